@@ -1,0 +1,161 @@
+/*
+ * ray_tracing_amd — C ABI of the MI355X-native path tracer (libray_tracing_amd.so).
+ *
+ * The reference (damnkk/Ray_tracing) has no plugin/FFI API: its operator boundary is the OpenGL hand-off in
+ * path_tracing_5chap/path_tracing_5chap.cpp (abbrev. c5) — two RGB32F texture buffers, two RGB32F 2-D textures, a few
+ * uniforms, one full-screen draw per frame.  Each entry point below cites the reference interface it replaces
+ * (c2 = path_tracing_2chap/path_tracing_2.cpp, c4 = path_tracing_4chap/path_tracing_4.cpp,
+ *  f3/f4/f5 = path_tracing_{3,4,5}chap/shaders/fshader.fsh, hdr = path_tracing_5chap/lib/hdrloader.cpp).
+ *
+ * Conventions: every function returns RT_OK (0) or a negative rt_status; rt_last_error() gives the message of the last
+ * failure on the calling thread.  Nothing aborts.  All floats are IEEE fp32; all arrays are plain C arrays.
+ * Images are in GL row order (row 0 = bottom row), 3 floats per pixel, as pass1 writes them (f5:987).
+ */
+#ifndef RAY_TRACING_AMD_H
+#define RAY_TRACING_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,
+    RT_ERR_IO = -2,
+    RT_ERR_FORMAT = -3,
+    RT_ERR_HIP = -4,
+    RT_ERR_NO_DEVICE = -5,
+    RT_ERR_BAD_BVH = -6,
+    RT_ERR_OOM = -7
+} rt_status;
+
+const char* rt_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Host scene layer (CPU, C++): produces exactly the arrays the reference uploads.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Disney material parameter block — field order of `struct Material`, c5:23-39 (= texels 6..11 of Triangle_encoded). */
+typedef struct rt_material {
+    float emissive[3];
+    float baseColor[3];
+    float subsurface, metallic, specular;
+    float specularTint, roughness, anisotropic;
+    float sheen, sheenTint, clearcoat;
+    float clearcoatGloss, IOR, transmission;
+} rt_material;
+
+/* Defaults of c5:25-38: emissive 0, baseColor 1, IOR 1, everything else 0. */
+void rt_material_default(rt_material* m);
+
+/* A growable list of Triangle_encoded records (c5:54-64): 36 floats = 144 B per triangle,
+ * p1 p2 p3 n1 n2 n3 emissive baseColor param1..param4. */
+typedef struct rt_mesh rt_mesh;
+int rt_mesh_create(rt_mesh** out);
+void rt_mesh_destroy(rt_mesh* m);
+int rt_mesh_count(const rt_mesh* m);
+const float* rt_mesh_data(const rt_mesh* m); /* valid until the mesh is next modified */
+int rt_mesh_append(rt_mesh* m, const float* tris36, int n_triangles);
+
+/* getTransformMatrix, c5:249-265: translate * rotX*rotY*rotZ * scale, angles in degrees; column-major 4x4 out. */
+int rt_transform_matrix(const float rotate_deg[3], const float translate[3], const float scale[3], float out16[16]);
+
+/* readObj of chapters 3-5, c5:267-397: `v`, `f a b c | a/b | a/b/c` (by slash count), unit max-extent normalisation,
+ * `trans` (column-major), smooth (area-unweighted) or flat normals, `material` copied per triangle; appends. */
+int rt_mesh_read_obj(rt_mesh* m, const char* path, const rt_material* material, const float trans16[16], int smooth_normal);
+
+/* readObj of chapter 2, c2:142-183 (positions + `f a b c` only, no normalisation), followed by the vertex edit of
+ * c2:590-594 (`v *= scale; v.y -= y_offset`).  Triangles get flat normals and the default material; appends. */
+int rt_mesh_read_obj_chap2(rt_mesh* m, const char* path, float scale, float y_offset);
+
+/* buildBVHwithSAH (use_sah != 0, c5:462-593 / c2:309-436) or buildBVH (c5:399-460) over the whole mesh with leaf size
+ * `leaf_n` (the reference passes 8, c5:843).  Permutes the mesh in place exactly as the reference's std::sort calls do
+ * and returns BVHNode_encoded records (c5:65-70; 12 floats = 48 B per node) with the dummy node at index 0 and the
+ * root at index 1 (c5:835-843).  Node 0's fields are zeroed (the reference leaves `index` uninitialised).
+ * `*nodes_out` is released with rt_free. */
+int rt_bvh_build(rt_mesh* m, int leaf_n, int use_sah, float** nodes_out, int* n_nodes);
+
+/* HDRLoader::load, hdr:29-97 (Radiance RGBE, new and old RLE; rows in file order, top scanline first).
+ * The resolution line is parsed with %d (the reference's %ld into int is UB on LP64).  `*rgb` released with rt_free. */
+int rt_hdr_load(const char* path, int* width, int* height, float** rgb);
+
+/* calculateHdrCache, c5:595-698: W*H*3 floats (x/W, y/H, pdf) from marginal/conditional CDF inversion. */
+int rt_hdr_cache(const float* rgb, int width, int height, float* cache_out);
+
+/* Orbit camera of display(), c5:716-720: eye = r*(-sin(rot)cos(up), sin(up), cos(rot)cos(up)),
+ * cameraRotate = inverse(lookAt(eye, 0, +Y)), column-major. */
+int rt_camera(float rotat_angle_deg, float up_angle_deg, float r, float eye[3], float camera_rotate16[16]);
+
+/* pass3.fsh:14-25: c/(1+lum/1.5), pow(c,1/2.2), then GL's clamp + round-to-nearest 8-bit conversion.
+ * flip_y != 0 writes the top row first (what a PNG wants). */
+int rt_tonemap_rgb8(const float* rgb, int width, int height, unsigned char* out_rgb8, int flip_y);
+
+/* svpng(), path_tracing_1chap/svpng.inc:77-108: stored-deflate PNG, byte-identical output.  alpha != 0 => RGBA in. */
+int rt_write_png(const char* path, int width, int height, const unsigned char* img, int alpha);
+
+void rt_free(void* p);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Device layer (HIP, gfx950): the per-pixel path loop.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Replaces the GL context: binds the calling thread's library state to HIP device `device`. */
+int rt_init(int device);
+
+/* Replaces the TBO / texture uploads of c5:881-909.  `tris` = Triangle_encoded[nT] (36 floats each), `nodes` =
+ * BVHNode_encoded[nN] (12 floats each, root at 1), `hdr_map`/`hdr_cache` = RGB32F W*H (row 0 = first uploaded row) or
+ * NULL.  The library copies (like glBufferData); the BVH is validated (RT_ERR_BAD_BVH) before any kernel can see it. */
+typedef struct rt_scene rt_scene;
+int rt_scene_create(const float* tris, int n_triangles, const float* nodes, int n_nodes, const float* hdr_map,
+                    const float* hdr_cache, int hdr_width, int hdr_height, rt_scene** out);
+void rt_scene_destroy(rt_scene* s);
+
+enum { RT_MODE_CHAP3 = 3, RT_MODE_CHAP4 = 4, RT_MODE_CHAP5 = 5 }; /* which fshader.fsh main() to run */
+enum { RT_ACCUM_RUNNING_MEAN = 0, /* color = mix(last, color, 1/(frameCounter+1)), f5:954-955 */
+       RT_ACCUM_SUM = 1 /* accum += color (spp-split across GPUs; divide after the reduce) */ };
+
+/* The uniforms of f5:8-23 / c5:726-730, 923-928. */
+typedef struct rt_render_desc {
+    int32_t width, height;     /* uniform width,height */
+    int32_t mode;              /* RT_MODE_* */
+    int32_t max_bounce;        /* literal 4 at f5:949, 6 at f4:564 / f3; <=0 selects the reference literal */
+    int32_t accumulate;        /* RT_ACCUM_* */
+    float eye[3];              /* uniform eye */
+    float camera_rotate[16];   /* uniform cameraRotate, column-major (GL_FALSE transpose, c5:728) */
+} rt_render_desc;
+
+/* pass1.draw() for frameCounter = frame_begin .. frame_begin+frame_count-1 (c5:729, 755).  `accum` (W*H*3 fp32) is
+ * `lastFrame` on entry and the new `lastFrame` on return.  rt_render takes host memory and is synchronous;
+ * rt_render_device takes device memory and enqueues on `hip_stream` (a hipStream_t, NULL = default stream). */
+int rt_render(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_host);
+int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_dev,
+                     void* hip_stream);
+
+/* hitBVH of chapter 2 (c2:490-513) for the un-jittered camera rays of rt_render_desc: per pixel the index of the
+ * closest triangle (-1 = miss) and its distance, with chapter 2's tie rule (equal distance => the candidate in the
+ * right-most leaf, lowest index within a leaf). */
+int rt_primary_hits(rt_scene* s, const rt_render_desc* d, int32_t* tri_index_host, float* distance_host);
+int rt_primary_hits_device(rt_scene* s, const rt_render_desc* d, int32_t* tri_index_dev, float* distance_dev,
+                           void* hip_stream);
+
+/* Traversal statistics of a render (same rays as rt_render): totals over all hitBVH invocations. */
+typedef struct rt_trace_stats {
+    uint64_t paths;            /* pixel samples */
+    uint64_t rays;             /* hitBVH invocations (f5:259) */
+    uint64_t internal_nodes;   /* internal nodes popped  (I)  */
+    uint64_t leaf_nodes;       /* leaf nodes popped      (Lf) */
+    uint64_t triangles_tested; /* hitTriangle calls      (T)  */
+    uint64_t hit_updates;      /* closest-hit improvements inside hitArray (H), f5:250-253 */
+} rt_trace_stats;
+int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out);
+
+/* Average duration (ms) of the path-loop kernel launches made by the calling thread since the last call with
+ * reset != 0, measured with HIP events on the launch stream; *launches receives the count. */
+int rt_kernel_time_ms(float* avg_ms, int* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

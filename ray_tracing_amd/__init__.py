@@ -1,0 +1,290 @@
+"""ray_tracing_amd — MI355X-native path tracer behind the reference's data layout.
+
+Thin ctypes mirror of the C ABI in ``include/ray_tracing_amd.h`` (libray_tracing_amd.so: host scene layer in C++ +
+hand-written HIP kernels for gfx950).  Function names follow the reference's host code
+(path_tracing_5chap/path_tracing_5chap.cpp): ``readObj``, ``getTransformMatrix``, ``buildBVHwithSAH``,
+``calculateHdrCache``, ``HDRLoader.load`` ...  There is no CPU fallback: if the shared library is missing the import
+fails, and device entry points fail when no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libray_tracing_amd.so")
+ASSETS = os.path.join(os.path.dirname(_HERE), "assets")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C ray_tracing_amd/csrc` (or __graft_entry__.build()); "
+        "ray_tracing_amd has no fallback path")
+
+_lib = C.CDLL(LIB_PATH)
+
+RT_MODE_CHAP3, RT_MODE_CHAP4, RT_MODE_CHAP5 = 3, 4, 5
+RT_ACCUM_RUNNING_MEAN, RT_ACCUM_SUM = 0, 1
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+class Material(C.Structure):
+    """struct Material, path_tracing_5chap.cpp:23-39 (same field order, same defaults)."""
+    _fields_ = [("emissive", C.c_float * 3), ("baseColor", C.c_float * 3)] + [
+        (n, C.c_float) for n in ("subsurface", "metallic", "specular", "specularTint", "roughness", "anisotropic",
+                                 "sheen", "sheenTint", "clearcoat", "clearcoatGloss", "IOR", "transmission")]
+
+    def __init__(self, **kw):
+        super().__init__()
+        _lib.rt_material_default(C.byref(self))
+        for k, v in kw.items():
+            if k in ("emissive", "baseColor"):
+                getattr(self, k)[:] = list(v)
+            else:
+                setattr(self, k, v)
+
+    def as_array(self) -> np.ndarray:
+        return np.frombuffer(bytes(self), dtype=np.float32).copy()
+
+
+class RenderDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("mode", C.c_int32), ("max_bounce", C.c_int32),
+                ("accumulate", C.c_int32), ("eye", C.c_float * 3), ("camera_rotate", C.c_float * 16)]
+
+
+class TraceStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("paths", "rays", "internal_nodes", "leaf_nodes", "triangles_tested",
+                                          "hit_updates")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[rt_status {code}] {msg}")
+        self.code = code
+
+
+_lib.rt_last_error.restype = C.c_char_p
+_lib.rt_mesh_data.restype = _f32p
+_lib.rt_mesh_data.argtypes = [C.c_void_p]
+_lib.rt_mesh_count.argtypes = [C.c_void_p]
+_lib.rt_mesh_destroy.argtypes = [C.c_void_p]
+_lib.rt_mesh_destroy.restype = None
+_lib.rt_mesh_append.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+_lib.rt_mesh_read_obj.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Material), _f32p, C.c_int]
+_lib.rt_mesh_read_obj_chap2.argtypes = [C.c_void_p, C.c_char_p, C.c_float, C.c_float]
+_lib.rt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(_f32p), C.POINTER(C.c_int)]
+_lib.rt_hdr_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_f32p)]
+_lib.rt_hdr_cache.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+_lib.rt_camera.argtypes = [C.c_float, C.c_float, C.c_float, _f32p, _f32p]
+_lib.rt_tonemap_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+_lib.rt_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+_lib.rt_free.argtypes = [C.c_void_p]
+_lib.rt_free.restype = None
+_lib.rt_scene_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.POINTER(C.c_void_p)]
+_lib.rt_scene_destroy.argtypes = [C.c_void_p]
+_lib.rt_scene_destroy.restype = None
+_lib.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p]
+_lib.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+_lib.rt_primary_hits.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p]
+_lib.rt_primary_hits_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
+_lib.rt_kernel_time_ms.argtypes = [_f32p, C.POINTER(C.c_int), C.c_int]
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise RtError(rc, _lib.rt_last_error().decode(errors="replace"))
+
+
+def lib() -> C.CDLL:
+    """The raw C ABI (for callers that want to bind it themselves)."""
+    return _lib
+
+
+def getTransformMatrix(rotateCtrl, translateCtrl, scaleCtrl) -> np.ndarray:
+    """getTransformMatrix, c5:249-265.  Returns the column-major 4x4 as 16 floats."""
+    out = (C.c_float * 16)()
+    _check(_lib.rt_transform_matrix((C.c_float * 3)(*rotateCtrl), (C.c_float * 3)(*translateCtrl),
+                                    (C.c_float * 3)(*scaleCtrl), out))
+    return np.array(out[:], dtype=np.float32)
+
+
+class Mesh:
+    """std::vector<Triangle> of the reference, stored as Triangle_encoded records (c5:54-64)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(_lib.rt_mesh_create(C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.rt_mesh_destroy(self._h)
+            self._h = None
+
+    def __len__(self):
+        return _lib.rt_mesh_count(self._h)
+
+    def readObj(self, filepath: str, material: Material, trans, smoothNormal: bool):
+        """readObj, c5:267-397."""
+        t = np.ascontiguousarray(trans, dtype=np.float32).reshape(16)
+        _check(_lib.rt_mesh_read_obj(self._h, filepath.encode(), C.byref(material), t.ctypes.data_as(_f32p),
+                                     1 if smoothNormal else 0))
+
+    def readObjChap2(self, filepath: str, scale: float = 1.0, y_offset: float = 0.0):
+        """readObj, c2:142-183 (+ the vertex edit of c2:590-594)."""
+        _check(_lib.rt_mesh_read_obj_chap2(self._h, filepath.encode(), scale, y_offset))
+
+    def append(self, tris36: np.ndarray):
+        a = np.ascontiguousarray(tris36, dtype=np.float32).reshape(-1, 36)
+        _check(_lib.rt_mesh_append(self._h, a.ctypes.data, a.shape[0]))
+
+    def triangles(self) -> np.ndarray:
+        """Triangle_encoded[n] as an (n, 36) float32 array (a copy)."""
+        n = len(self)
+        if n == 0:
+            return np.zeros((0, 36), np.float32)
+        return np.ctypeslib.as_array(_lib.rt_mesh_data(self._h), shape=(n, 36)).copy()
+
+    def buildBVHwithSAH(self, n: int = 8) -> np.ndarray:
+        """buildBVHwithSAH(triangles, nodes, 0, size-1, n), c5:462-593 + encode c5:869-875.  Permutes the mesh."""
+        return self._build(n, 1)
+
+    def buildBVH(self, n: int = 8) -> np.ndarray:
+        """buildBVH, c5:399-460."""
+        return self._build(n, 0)
+
+    def _build(self, n, sah):
+        p = _f32p()
+        cnt = C.c_int()
+        _check(_lib.rt_bvh_build(self._h, n, sah, C.byref(p), C.byref(cnt)))
+        try:
+            return np.ctypeslib.as_array(p, shape=(cnt.value, 12)).copy()
+        finally:
+            _lib.rt_free(p)
+
+
+def loadHDR(path: str) -> np.ndarray:
+    """HDRLoader::load, lib/hdrloader.cpp:29-97 -> (H, W, 3) float32, top scanline first."""
+    w, h, p = C.c_int(), C.c_int(), _f32p()
+    _check(_lib.rt_hdr_load(path.encode(), C.byref(w), C.byref(h), C.byref(p)))
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+    finally:
+        _lib.rt_free(p)
+
+
+def calculateHdrCache(hdr: np.ndarray) -> np.ndarray:
+    """calculateHdrCache, c5:595-698."""
+    hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+    out = np.empty_like(hdr)
+    _check(_lib.rt_hdr_cache(hdr.ctypes.data, hdr.shape[1], hdr.shape[0], out.ctypes.data))
+    return out
+
+
+def camera(rotatAngle: float = 0.0, upAngle: float = 0.0, r: float = 4.0):
+    """eye / cameraRotate of display(), c5:716-720."""
+    eye = (C.c_float * 3)()
+    cam = (C.c_float * 16)()
+    _check(_lib.rt_camera(rotatAngle, upAngle, r, eye, cam))
+    return np.array(eye[:], np.float32), np.array(cam[:], np.float32)
+
+
+def tonemap_rgb8(rgb: np.ndarray, flip_y: bool = True) -> np.ndarray:
+    """pass3.fsh:14-25 + 8-bit conversion."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[:2]
+    out = np.empty((h, w, 3), np.uint8)
+    _check(_lib.rt_tonemap_rgb8(rgb.ctypes.data, w, h, out.ctypes.data, 1 if flip_y else 0))
+    return out
+
+
+def write_png(path: str, img: np.ndarray):
+    """svpng(), path_tracing_1chap/svpng.inc:77-108."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, c = img.shape
+    _check(_lib.rt_write_png(path.encode(), w, h, img.ctypes.data, 1 if c == 4 else 0))
+
+
+def make_desc(width, height, mode=RT_MODE_CHAP5, eye=(0, 0, 4), camera_rotate=None, max_bounce=0,
+              accumulate=RT_ACCUM_RUNNING_MEAN) -> RenderDesc:
+    d = RenderDesc()
+    d.width, d.height, d.mode, d.max_bounce, d.accumulate = width, height, mode, max_bounce, accumulate
+    d.eye[:] = [float(x) for x in eye]
+    if camera_rotate is None:
+        camera_rotate = np.eye(4, dtype=np.float32).reshape(16)
+    d.camera_rotate[:] = [float(x) for x in np.asarray(camera_rotate).reshape(16)]
+    return d
+
+
+class Scene:
+    """Device-resident scene: what c5:881-909 uploads (triangles TBO, nodes TBO, hdrMap, hdrCache)."""
+
+    def __init__(self, triangles: np.ndarray, nodes: np.ndarray, hdr: np.ndarray | None = None,
+                 hdr_cache: np.ndarray | None = None, device: int | None = None):
+        if device is not None:
+            _check(_lib.rt_init(device))
+        tris = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 36)
+        nd = np.ascontiguousarray(nodes, dtype=np.float32).reshape(-1, 12)
+        self.n_triangles, self.n_nodes = tris.shape[0], nd.shape[0]
+        hw = hh = 0
+        hp = cp = None
+        if hdr is not None:
+            hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+            hh, hw = hdr.shape[:2]
+            hp = hdr.ctypes.data
+            if hdr_cache is not None:
+                hdr_cache = np.ascontiguousarray(hdr_cache, dtype=np.float32)
+                assert hdr_cache.shape == hdr.shape
+                cp = hdr_cache.ctypes.data
+        self._h = C.c_void_p()
+        _check(_lib.rt_scene_create(tris.ctypes.data if tris.size else None, tris.shape[0],
+                                    nd.ctypes.data if nd.size else None, nd.shape[0], hp, cp, hw, hh,
+                                    C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.rt_scene_destroy(self._h)
+            self._h = None
+
+    def render(self, desc: RenderDesc, frame_begin: int, frame_count: int, accum: np.ndarray | None = None) -> np.ndarray:
+        """pass1.draw() for frameCounter in [frame_begin, frame_begin+frame_count); accum is lastFrame (host)."""
+        if accum is None:
+            accum = np.zeros((desc.height, desc.width, 3), np.float32)
+        assert accum.dtype == np.float32 and accum.flags.c_contiguous and accum.size == desc.width * desc.height * 3
+        _check(_lib.rt_render(self._h, C.byref(desc), frame_begin, frame_count, accum.ctypes.data))
+        return accum
+
+    def render_device(self, desc: RenderDesc, frame_begin: int, frame_count: int, accum_ptr: int, stream: int = 0):
+        """Same on device memory (accum_ptr = device address of W*H*3 fp32), asynchronous on `stream`."""
+        _check(_lib.rt_render_device(self._h, C.byref(desc), frame_begin, frame_count, C.c_void_p(accum_ptr),
+                                     C.c_void_p(stream)))
+
+    def primary_hits(self, desc: RenderDesc):
+        """Chapter-2 hitBVH (c2:490-513) for the un-jittered camera rays: (tri index int32, distance fp32)."""
+        tri = np.empty((desc.height, desc.width), np.int32)
+        dist = np.empty((desc.height, desc.width), np.float32)
+        _check(_lib.rt_primary_hits(self._h, C.byref(desc), tri.ctypes.data, dist.ctypes.data))
+        return tri, dist
+
+    def primary_hits_device(self, desc: RenderDesc, tri_ptr: int, dist_ptr: int, stream: int = 0):
+        _check(_lib.rt_primary_hits_device(self._h, C.byref(desc), C.c_void_p(tri_ptr), C.c_void_p(dist_ptr),
+                                           C.c_void_p(stream)))
+
+    def render_stats(self, desc: RenderDesc, frame_begin: int, frame_count: int) -> dict:
+        st = TraceStats()
+        _check(_lib.rt_render_stats(self._h, C.byref(desc), frame_begin, frame_count, C.byref(st)))
+        return st.as_dict()
+
+
+def kernel_time_ms(reset: bool = True):
+    """(average ms, launches) of this thread's path-loop kernel launches since the last reset (HIP events)."""
+    ms, n = C.c_float(), C.c_int()
+    _check(_lib.rt_kernel_time_ms(C.byref(ms), C.byref(n), 1 if reset else 0))
+    return ms.value, n.value

@@ -1,0 +1,850 @@
+// Device layer: scene upload/validation/repacking and the HIP kernels of the per-pixel path loop (gfx950).
+//
+// Replaces pass1.draw() of the reference (c5:755 -> fshader.fsh main()).  One lane owns one pixel and walks
+// frameCounter = frame_begin .. frame_begin+frame_count-1 in order, so the fp32 running mean of f5:954-955 is
+// reproduced exactly.  BVH traversal visits nodes in the reference's order without culling (f5:259-311), on a
+// device-private repack of the reference arrays:
+//   * node record (64 B): both children's boxes + packed child entries -> one record per internal visit instead of the
+//     reference's 3 x 48 B node fetches;
+//   * traversal triangle (48 B): p1 p2 p3 + the plane normal normalize(cross(p2-p1,p3-p1)) precomputed with the
+//     identical fp32 sequence (f5:180) -> no sqrt/div per test; vertex normals + material (the other 96 B of
+//     Triangle_encoded) are fetched once per closest hit, not per improvement (f5:250-253).
+// Per-lane traversal stacks live in LDS ([depth][lane] layout, conflict-free), with a global spill only for trees deeper
+// than the LDS stack.  Environment-visibility rays (f5:863-869) only need isHit, so they stop at the first hit.
+// No MFMA: nothing here is a dense contraction.  Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "rt_host.h"
+#include "rt_shade.h"
+
+namespace rta {
+
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return set_error(RT_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                               __FILE__, __LINE__);                                        \
+    } while (0)
+
+constexpr int kBlock = 256;      // 16x16 pixels; each wave64 owns an 8x8 sub-tile
+constexpr int kLdsDepth = 32;    // per-lane stack entries kept in LDS
+constexpr int kMaxStack = 256;   // int stack[256], f5:265
+
+// Sobol direction numbers, f5:339 (data table: 8 dimensions x 32 bits)
+__device__ const unsigned d_sobolV[8 * 32] = {
+    2147483648u, 1073741824u, 536870912u, 268435456u, 134217728u, 67108864u, 33554432u, 16777216u, 8388608u, 4194304u, 2097152u, 1048576u, 524288u, 262144u, 131072u, 65536u, 32768u, 16384u, 8192u, 4096u, 2048u, 1024u, 512u, 256u, 128u, 64u, 32u, 16u, 8u, 4u, 2u, 1u,
+    2147483648u, 3221225472u, 2684354560u, 4026531840u, 2281701376u, 3422552064u, 2852126720u, 4278190080u, 2155872256u, 3233808384u, 2694840320u, 4042260480u, 2290614272u, 3435921408u, 2863267840u, 4294901760u, 2147516416u, 3221274624u, 2684395520u, 4026593280u, 2281736192u, 3422604288u, 2852170240u, 4278255360u, 2155905152u, 3233857728u, 2694881440u, 4042322160u, 2290649224u, 3435973836u, 2863311530u, 4294967295u,
+    2147483648u, 3221225472u, 1610612736u, 2415919104u, 3892314112u, 1543503872u, 2382364672u, 3305111552u, 1753219072u, 2629828608u, 3999268864u, 1435500544u, 2154299392u, 3231449088u, 1626210304u, 2421489664u, 3900735488u, 1556135936u, 2388680704u, 3314585600u, 1751705600u, 2627492864u, 4008611328u, 1431684352u, 2147543168u, 3221249216u, 1610649184u, 2415969680u, 3892340840u, 1543543964u, 2382425838u, 3305133397u,
+    2147483648u, 3221225472u, 536870912u, 1342177280u, 4160749568u, 1946157056u, 2717908992u, 2466250752u, 3632267264u, 624951296u, 1507852288u, 3872391168u, 2013790208u, 3020685312u, 2181169152u, 3271884800u, 546275328u, 1363623936u, 4226424832u, 1977167872u, 2693105664u, 2437829632u, 3689389568u, 635137280u, 1484783744u, 3846176960u, 2044723232u, 3067084880u, 2148008184u, 3222012020u, 537002146u, 1342505107u,
+    2147483648u, 1073741824u, 536870912u, 2952790016u, 4160749568u, 3690987520u, 2046820352u, 2634022912u, 1518338048u, 801112064u, 2707423232u, 4038066176u, 3666345984u, 1875116032u, 2170683392u, 1085997056u, 579305472u, 3016343552u, 4217741312u, 3719483392u, 2013407232u, 2617981952u, 1510979072u, 755882752u, 2726789248u, 4090085440u, 3680870432u, 1840435376u, 2147625208u, 1074478300u, 537900666u, 2953698205u,
+    2147483648u, 1073741824u, 1610612736u, 805306368u, 2818572288u, 335544320u, 2113929216u, 3472883712u, 2290089984u, 3829399552u, 3059744768u, 1127219200u, 3089629184u, 4199809024u, 3567124480u, 1891565568u, 394297344u, 3988799488u, 920674304u, 4193267712u, 2950604800u, 3977188352u, 3250028032u, 129093376u, 2231568512u, 2963678272u, 4281226848u, 432124720u, 803643432u, 1633613396u, 2672665246u, 3170194367u,
+    2147483648u, 3221225472u, 2684354560u, 3489660928u, 1476395008u, 2483027968u, 1040187392u, 3808428032u, 3196059648u, 599785472u, 505413632u, 4077912064u, 1182269440u, 1736704000u, 2017853440u, 2221342720u, 3329785856u, 2810494976u, 3628507136u, 1416089600u, 2658719744u, 864310272u, 3863387648u, 3076993792u, 553150080u, 272922560u, 4167467040u, 1148698640u, 1719673080u, 2009075780u, 2149644390u, 3222291575u,
+    2147483648u, 1073741824u, 2684354560u, 1342177280u, 2281701376u, 1946157056u, 436207616u, 2566914048u, 2625634304u, 3208642560u, 2720006144u, 2098200576u, 111673344u, 2354315264u, 3464626176u, 4027383808u, 2886631424u, 3770826752u, 1691164672u, 3357462528u, 1993345024u, 3752330240u, 873073152u, 2870150400u, 1700563072u, 87021376u, 1097028000u, 1222351248u, 1560027592u, 2977959924u, 23268898u, 437609937u};
+
+// ---- device view of a scene ------------------------------------------------------------------------------------
+struct DevScene {
+    const float4* ttri;   // 3 x float4 per triangle: (p1.xyz,p2.x) (p2.yz,p3.xy) (p3.z,N.xyz)
+    const float* tris;    // Triangle_encoded[nT], the caller's layout
+    const float4* nodes;  // 4 x float4 per internal node: (lAA,lBB.x) (lBB.yz,rAA.xy) (rAA.z,rBB) (lentry,rentry,-,-)
+    const float4* hdr;    // hdrMap as RGBX
+    const float4* cache;  // hdrCache as RGBX
+    int hdrW, hdrH;
+    int root_entry;       // packed entry of node 1
+    int has_root;
+};
+
+// packed stack entry: >= 0 internal record index; < 0 leaf: bit31 | (n-1) << 24 | first triangle index
+__host__ __device__ inline int pack_leaf(int index, int n) { return (int)(0x80000000u | ((unsigned)(n - 1) << 24) | (unsigned)index); }
+
+struct Stats {
+    unsigned rays, internal, leaves, tris, updates;
+};
+
+struct RenderParams {
+    DevScene sc;
+    int width, height, max_bounce, accumulate;
+    int frame_begin, frame_count;
+    float eye[3];
+    float cam[16];
+    float* accum;
+    int* spill;            // global stack spill, [depth - kLdsDepth][thread]
+    long long spill_stride;
+    unsigned long long* stats;  // 6 counters (STATS builds)
+    int32_t* hit_tri;      // primary-hit query outputs
+    float* hit_dist;
+};
+
+// ---- T2: hitAABB, f5:225-238 ------------------------------------------------------------------------------------
+__device__ __forceinline__ float hitAABB(vec3 S, vec3 invdir, vec3 AA, vec3 BB) {
+    const vec3 f = (BB - S) * invdir;
+    const vec3 n = (AA - S) * invdir;
+    const vec3 tmax = max3(f, n);
+    const vec3 tmin = min3(f, n);
+    const float t1 = fmin_(tmax.x, fmin_(tmax.y, tmax.z));
+    const float t0 = fmax_(tmin.x, fmax_(tmin.y, tmin.z));
+    return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+}
+
+// ---- T1: hitTriangle (distance part), f5:168-209.  N0 = precomputed normalize(cross(p2-p1, p3-p1)). -------------
+__device__ __forceinline__ bool hitTriangleT(vec3 p1, vec3 p2, vec3 p3, vec3 N0, vec3 S, vec3 d, float* t_out) {
+    vec3 N = N0;
+    if (dot(N, d) > 0.0f) N = -N;
+    if (fabs_(dot(N, d)) < 0.00001f) return false;
+    const float t = (dot(N, p1) - dot(S, N)) / dot(d, N);
+    if (t < 0.0005f) return false;
+    const vec3 P = S + d * t;
+    const vec3 c1 = cross(p2 - p1, P - p1);
+    const vec3 c2 = cross(p3 - p2, P - p2);
+    const vec3 c3 = cross(p1 - p3, P - p3);
+    const float a = dot(c1, N), b = dot(c2, N), c = dot(c3, N);
+    const bool r1 = (a > 0.0f && b > 0.0f && c > 0.0f);
+    const bool r2 = (a < 0.0f && b < 0.0f && c < 0.0f);
+    if (!(r1 || r2)) return false;
+    *t_out = t;
+    return true;
+}
+
+struct LaneStack {
+    int* lds;              // &s_stack[threadIdx.x]; entry k at lds[k * kBlock]
+    int* spill;            // &spill[global thread]; entry k at spill[(k - kLdsDepth) * stride]
+    long long stride;
+};
+
+template <bool SPILL>
+__device__ __forceinline__ void stack_push(const LaneStack& st, int sp, int v) {
+    if (!SPILL || sp < kLdsDepth)
+        st.lds[sp * kBlock] = v;
+    else
+        st.spill[(long long)(sp - kLdsDepth) * st.stride] = v;
+}
+template <bool SPILL>
+__device__ __forceinline__ int stack_pop(const LaneStack& st, int sp) {
+    if (!SPILL || sp < kLdsDepth) return st.lds[sp * kBlock];
+    return st.spill[(long long)(sp - kLdsDepth) * st.stride];
+}
+
+enum TieRule { TIE_SHADER = 0, TIE_CHAP2 = 1 };
+
+// ---- T3/T4: hitArray + hitBVH, f5:243-311 (TIE_SHADER) / c2:451-513 (TIE_CHAP2) --------------------------------
+// Returns the closest triangle index (-1 = miss) and its distance.  ANYHIT returns at the first accepted hit.
+template <bool ANYHIT, int TIE, bool STATS, bool SPILL>
+__device__ __forceinline__ int hitBVH(const DevScene& sc, const LaneStack& stk, vec3 S, vec3 d, float* dist, Stats& st) {
+    float best = INF_;
+    int best_tri = -1;
+    int best_first = -1;
+    if (STATS) st.rays++;
+    if (!sc.has_root) {
+        *dist = best;
+        return -1;
+    }
+    const vec3 invdir = v3(1.0f) / d;
+    int sp = 0;
+    int cur = sc.root_entry;
+    while (true) {
+        if (cur >= 0) {
+            if (STATS) st.internal++;
+            const float4 q0 = sc.nodes[cur * 4 + 0], q1 = sc.nodes[cur * 4 + 1], q2 = sc.nodes[cur * 4 + 2],
+                         q3 = sc.nodes[cur * 4 + 3];
+            const float d1 = hitAABB(S, invdir, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y));
+            const float d2 = hitAABB(S, invdir, v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w));
+            const int le = __float_as_int(q3.x), re = __float_as_int(q3.y);
+            if (d1 > 0.0f && d2 > 0.0f) {
+                if (d1 < d2) {  // left first
+                    stack_push<SPILL>(stk, sp++, re);
+                    cur = le;
+                } else {        // right first (ties included)
+                    stack_push<SPILL>(stk, sp++, le);
+                    cur = re;
+                }
+                continue;
+            } else if (d1 > 0.0f) {
+                cur = le;
+                continue;
+            } else if (d2 > 0.0f) {
+                cur = re;
+                continue;
+            }
+        } else {
+            if (STATS) st.leaves++;
+            const int first = cur & 0x00ffffff;
+            const int n = ((cur >> 24) & 0x7f) + 1;
+            for (int i = first; i < first + n; ++i) {
+                const float4 a = sc.ttri[i * 3 + 0], b = sc.ttri[i * 3 + 1], c = sc.ttri[i * 3 + 2];
+                float t;
+                if (STATS) st.tris++;
+                if (hitTriangleT(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), S, d, &t)) {
+                    // shader (f5:250, 278): strict < in visit order => the first visited candidate keeps a tie.
+                    // chap2 (c2:457, 512): minimum over all visited leaves; a tie goes to the right-most leaf
+                    // (larger first index) and, inside a leaf, to the lowest index.
+                    bool better;
+                    if (TIE == TIE_CHAP2)
+                        better = (t < best) || (t == best && first > best_first);
+                    else
+                        better = t < best;
+                    if (better) {
+                        if (STATS) st.updates++;
+                        best = t;
+                        best_tri = i;
+                        best_first = first;
+                        if (ANYHIT) {
+                            *dist = best;
+                            return best_tri;
+                        }
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack_pop<SPILL>(stk, --sp);
+    }
+    *dist = best;
+    return best_tri;
+}
+
+
+// ---- rest of hitTriangle for the closest hit only (f5:205-219; f4/f3:393-406) ----------------------------------
+struct Hit {
+    vec3 hitPoint, normal, viewDir;
+    int tri;
+};
+
+template <int MODE>
+__device__ __forceinline__ Hit finish_hit(const DevScene& sc, vec3 S, vec3 d, int tri, float t) {
+    const float4 a = sc.ttri[tri * 3 + 0], b = sc.ttri[tri * 3 + 1], c = sc.ttri[tri * 3 + 2];
+    const vec3 p1 = v3(a.x, a.y, a.z), p2 = v3(a.w, b.x, b.y), p3 = v3(b.z, b.w, c.x), N0 = v3(c.y, c.z, c.w);
+    const float* T = sc.tris + (size_t)tri * 36;
+    const vec3 n1 = v3(T[9], T[10], T[11]), n2 = v3(T[12], T[13], T[14]), n3 = v3(T[15], T[16], T[17]);
+    const bool isInside = dot(N0, d) > 0.0f;
+    const vec3 P = S + d * t;
+    float alpha, beta;
+    if (MODE == RT_MODE_CHAP5) {
+        alpha = (-(P.x - p2.x) * (p3.y - p2.y) + (P.y - p2.y) * (p3.x - p2.x)) /
+                (-(p1.x - p2.x) * (p3.y - p2.y) + (p1.y - p2.y) * (p3.x - p2.x) + 1e-7f);
+        beta = (-(P.x - p3.x) * (p1.y - p3.y) + (P.y - p3.y) * (p1.x - p3.x)) /
+               (-(p2.x - p3.x) * (p1.y - p3.y) + (p2.y - p3.y) * (p1.x - p3.x) + 1e-7f);
+    } else {
+        alpha = (-(P.x - p2.x) * (p3.y - p2.y) + (P.y - p2.y) * (p3.x - p2.x)) /
+                (-(p1.x - p2.x - 0.00005f) * (p3.y - p2.y + 0.00005f) + (p1.y - p2.y + 0.00005f) * (p3.x - p2.x + 0.00005f));
+        beta = (-(P.x - p3.x) * (p1.y - p3.y) + (P.y - p3.y) * (p1.x - p3.x)) /
+               (-(p2.x - p3.x - 0.00005f) * (p1.y - p3.y + 0.00005f) + (p2.y - p3.y + 0.00005f) * (p1.x - p3.x + 0.00005f));
+    }
+    const float gama = 1.0f - alpha - beta;
+    vec3 Nsmooth = alpha * n1 + beta * n2 + gama * n3;
+    Nsmooth = normalize(Nsmooth);
+    Hit h;
+    h.hitPoint = P;
+    h.normal = isInside ? (-Nsmooth) : Nsmooth;
+    h.viewDir = d;
+    h.tri = tri;
+    return h;
+}
+
+__device__ __forceinline__ Mat load_material(const DevScene& sc, int tri) {
+    const float* T = sc.tris + (size_t)tri * 36 + 18;
+    Mat m;
+    m.emissive = v3(T[0], T[1], T[2]);
+    m.baseColor = v3(T[3], T[4], T[5]);
+    m.subsurface = T[6], m.metallic = T[7], m.specular = T[8];
+    m.specularTint = T[9], m.roughness = T[10], m.anisotropic = T[11];
+    m.sheen = T[12], m.sheenTint = T[13], m.clearcoat = T[14];
+    m.clearcoatGloss = T[15];
+    return m;
+}
+
+// ---- E1: hdrColor / sampleHdr, f5:638-644, f4:159-165 --------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ vec3 envColor(const DevScene& sc, vec3 v) {
+    if (!sc.hdr) return v3(0);
+    float u, w;
+    toSphericalCoord(normalize(v), &u, &w);
+    const float4 c = sc.hdr[texel_index(w, sc.hdrH) * sc.hdrW + texel_index(u, sc.hdrW)];
+    vec3 color = v3(c.x, c.y, c.z);
+    if (MODE != RT_MODE_CHAP5) color = min3(color, v3(10));
+    return color;
+}
+__device__ __forceinline__ float envPdf(const DevScene& sc, vec3 L) {  // hdrPdf, f5:648-660
+    float u, w;
+    toSphericalCoord(normalize(L), &u, &w);
+    const float4 c = sc.cache[texel_index(w, sc.hdrH) * sc.hdrW + texel_index(u, sc.hdrW)];
+    return hdrPdfConvert(c.z, w, sc.hdrW);
+}
+
+// ---- P1 / P1' / chap3: one pixel sample (fshader.fsh main() up to the frame blend) ------------------------------
+template <int MODE, bool STATS, bool SPILL>
+__device__ __forceinline__ vec3 trace_sample(const RenderParams& P, const LaneStack& stk, float pixx, float pixy,
+                                             unsigned frame, float cpu, float cpv, Stats& st) {
+    const DevScene& sc = P.sc;
+    unsigned seed = pixel_seed(pixx, pixy, P.width, P.height, frame);
+    const vec3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
+    const float aax = (rand01(seed) - 0.5f) / (float)P.width;
+    const float aay = (rand01(seed) - 0.5f) / (float)P.height;
+    const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
+    const float* m = P.cam;  // column-major: m[col*4+row]
+    vec3 dir;
+    dir.x = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
+    dir.y = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
+    dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
+    dir = normalize(dir);
+
+    float t;
+    int tri = hitBVH<false, TIE_SHADER, STATS, SPILL>(sc, stk, eye, dir, &t, st);
+    if (tri < 0) return envColor<MODE>(sc, dir);
+    Hit hit = finish_hit<MODE>(sc, eye, dir, tri, t);
+    Mat mat = load_material(sc, tri);
+    const vec3 Le0 = mat.emissive;
+
+    vec3 Lo = v3(0);
+    vec3 history = v3(1);
+    for (int bounce = 0; bounce < P.max_bounce; ++bounce) {
+        const vec3 V = -hit.viewDir;
+        const vec3 N = hit.normal;
+        if (MODE == RT_MODE_CHAP5) {  // f5:850-923
+            const float r1 = rand01(seed), r2 = rand01(seed);
+            const float4 ce = sc.cache[texel_index(r2, sc.hdrH) * sc.hdrW + texel_index(r1, sc.hdrW)];
+            const vec3 Lh = hdrDirection(ce.x, ce.y);
+            if (dot(N, Lh) > 0.0f) {
+                float th;
+                const int occl = hitBVH<true, TIE_SHADER, STATS, SPILL>(sc, stk, hit.hitPoint, Lh, &th, st);
+                if (occl < 0) {
+                    const vec3 color = envColor<MODE>(sc, Lh);
+                    const float pdf_light = envPdf(sc, Lh);
+                    float pdf_brdf;
+                    const vec3 f_r = disney_eval<false, true>(V, N, Lh, v3(0), v3(0), mat, &pdf_brdf);
+                    const float mis_weight = misMixWeight(pdf_light, pdf_brdf);
+                    Lo += mis_weight * history * color * f_r * dot(N, Lh) / pdf_light;
+                }
+            }
+            const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
+            const float su = sobol_dim(d_sobolV, bounce * 2, gray);
+            const float sv = sobol_dim(d_sobolV, bounce * 2 + 1, gray);
+            const float xi_1 = cp_rotate(su, cpu);
+            const float xi_2 = cp_rotate(sv, cpv);
+            const float xi_3 = rand01(seed);
+            const vec3 L = SampleBRDF(xi_1, xi_2, xi_3, V, N, mat);
+            const float NdotL = dot(N, L);
+            if (NdotL <= 0.0f) break;
+            tri = hitBVH<false, TIE_SHADER, STATS, SPILL>(sc, stk, hit.hitPoint, L, &t, st);
+            float pdf_brdf;
+            const vec3 f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
+            if (pdf_brdf <= 0.0f) break;
+            if (tri < 0) {
+                const vec3 color = envColor<MODE>(sc, L);
+                const float pdf_light = envPdf(sc, L);
+                const float mis_weight = misMixWeight(pdf_brdf, pdf_light);
+                Lo += mis_weight * history * color * NdotL * f_r / pdf_brdf;
+                break;
+            }
+            const Hit newhit = finish_hit<MODE>(sc, hit.hitPoint, L, tri, t);
+            mat = load_material(sc, tri);
+            Lo += history * mat.emissive * NdotL * f_r / pdf_brdf;
+            hit = newhit;
+            history *= NdotL * f_r / pdf_brdf;
+        } else {  // f4:505-541 (chap4) and f3:378-416 (chap3)
+            const vec3 L = toNormalHemisphere(SampleHemisphereRand(seed), N);
+            const float pdf = 1.0f / (2.0f * PI_);
+            const float cosine_i = fmax_(0.0f, dot(MODE == RT_MODE_CHAP4 ? N : L, MODE == RT_MODE_CHAP4 ? L : N));
+            vec3 f_r;
+            if (MODE == RT_MODE_CHAP4) {
+                vec3 tangent, bitangent;
+                getTagent(N, tangent, bitangent);
+                f_r = disney_eval<true, false>(V, N, L, tangent, bitangent, mat, nullptr);
+            } else {
+                f_r = mat.baseColor / PI_;
+            }
+            tri = hitBVH<false, TIE_SHADER, STATS, SPILL>(sc, stk, hit.hitPoint, L, &t, st);
+            if (tri < 0) {
+                const vec3 skyColor = envColor<MODE>(sc, L);
+                Lo += history * skyColor * f_r * cosine_i / pdf;
+                break;
+            }
+            const Hit newhit = finish_hit<MODE>(sc, hit.hitPoint, L, tri, t);
+            const Mat newmat = load_material(sc, tri);
+            if (MODE == RT_MODE_CHAP4)
+                Lo += history * newmat.emissive * cosine_i / pdf;  // f4:535: no f_r
+            else
+                Lo += history * newmat.emissive * f_r * cosine_i / pdf;  // f3:407
+            hit = newhit;
+            mat = newmat;
+            history *= f_r * cosine_i / pdf;
+        }
+    }
+    return Le0 + Lo;
+}
+
+__device__ __forceinline__ bool lane_pixel(const RenderParams& P, int* px, int* py) {
+    // block = 16x16 pixels, wave w = 8x8 sub-tile (w&1, w>>1), lane l = (l&7, l>>3)
+    const int tilesx = (P.width + 15) >> 4;
+    const int bx = blockIdx.x % tilesx, by = blockIdx.x / tilesx;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    *px = bx * 16 + (w & 1) * 8 + (l & 7);
+    *py = by * 16 + (w >> 1) * 8 + (l >> 3);
+    return *px < P.width && *py < P.height;
+}
+
+__device__ __forceinline__ void flush_stats(const RenderParams& P, const Stats& st, unsigned long long paths) {
+    unsigned long long v[6] = {paths, st.rays, st.internal, st.leaves, st.tris, st.updates};
+    for (int k = 0; k < 6; ++k) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&P.stats[k], x);
+    }
+}
+
+template <int MODE, bool STATS, bool SPILL>
+__global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
+    __shared__ int s_stack[kLdsDepth * kBlock];
+    int px, py;
+    const bool active = lane_pixel(P, &px, &py);
+    LaneStack stk;
+    stk.lds = &s_stack[threadIdx.x];
+    stk.stride = P.spill_stride;
+    stk.spill = SPILL ? (P.spill + ((long long)blockIdx.x * kBlock + threadIdx.x)) : nullptr;
+    Stats st = {0, 0, 0, 0, 0};
+    unsigned long long paths = 0;
+    if (active) {
+        // pix = interpolated quad position at the pixel centre (vshader.vsh:7-10), GL row order (row 0 = bottom)
+        const float pixx = -1.0f + 2.0f * ((float)px + 0.5f) / (float)P.width;
+        const float pixy = -1.0f + 2.0f * ((float)py + 0.5f) / (float)P.height;
+        float cpu = 0.0f, cpv = 0.0f;
+        if (MODE == RT_MODE_CHAP5) cp_shift(pixx, pixy, P.width, P.height, &cpu, &cpv);
+        float* out = P.accum + ((size_t)py * P.width + px) * 3;
+        vec3 acc = v3(out[0], out[1], out[2]);
+        for (int f = 0; f < P.frame_count; ++f) {
+            const unsigned frame = (unsigned)(P.frame_begin + f);
+            const vec3 color = trace_sample<MODE, STATS, SPILL>(P, stk, pixx, pixy, frame, cpu, cpv, st);
+            if (P.accumulate == RT_ACCUM_SUM)
+                acc = acc + color;
+            else
+                acc = mix3(acc, color, 1.0f / (float)(int)(frame + 1u));  // f5:955
+            if (STATS) paths++;
+        }
+        out[0] = acc.x, out[1] = acc.y, out[2] = acc.z;
+    }
+    if (STATS) flush_stats(P, st, paths);
+}
+
+// config 2: un-jittered camera rays, chapter-2 closest hit (c2:490-513)
+template <bool STATS, bool SPILL>
+__global__ void __launch_bounds__(kBlock) primary_kernel(const RenderParams P) {
+    __shared__ int s_stack[kLdsDepth * kBlock];
+    int px, py;
+    const bool active = lane_pixel(P, &px, &py);
+    LaneStack stk;
+    stk.lds = &s_stack[threadIdx.x];
+    stk.stride = P.spill_stride;
+    stk.spill = SPILL ? (P.spill + ((long long)blockIdx.x * kBlock + threadIdx.x)) : nullptr;
+    Stats st = {0, 0, 0, 0, 0};
+    if (active) {
+        const float vx = -1.0f + 2.0f * ((float)px + 0.5f) / (float)P.width;
+        const float vy = -1.0f + 2.0f * ((float)py + 0.5f) / (float)P.height;
+        const float vz = -1.5f, vw = 0.0f;
+        const float* m = P.cam;
+        vec3 dir;
+        dir.x = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
+        dir.y = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
+        dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
+        dir = normalize(dir);
+        float t;
+        const int tri = hitBVH<false, TIE_CHAP2, STATS, SPILL>(P.sc, stk, v3(P.eye[0], P.eye[1], P.eye[2]), dir, &t, st);
+        const size_t o = (size_t)py * P.width + px;
+        P.hit_tri[o] = tri;
+        P.hit_dist[o] = t;
+    }
+    if (STATS) flush_stats(P, st, active ? 1 : 0);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+
+struct TimedLaunch {
+    hipEvent_t a, b;
+};
+static thread_local std::vector<TimedLaunch> g_launches;
+static thread_local int g_device = -1;
+
+}  // namespace rta
+
+using namespace rta;
+
+struct rt_scene {
+    int device = 0;
+    int nT = 0, nN = 0;
+    int max_stack = 0;  // stack entries the deepest traversal can hold
+    DevScene dev{};
+    void* d_ttri = nullptr;
+    void* d_tris = nullptr;
+    void* d_nodes = nullptr;
+    void* d_hdr = nullptr;
+    void* d_cache = nullptr;
+    int* d_spill = nullptr;
+    size_t spill_bytes = 0;
+};
+
+static int f2i_checked(float f, int* out) {
+    if (!(f >= -1.0f && f < 16777216.0f)) return 0;
+    const int i = (int)f;
+    if ((float)i != f) return 0;
+    *out = i;
+    return 1;
+}
+
+extern "C" {
+
+int rt_init(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_error(RT_ERR_NO_DEVICE, "rt_init: no HIP device available");
+    if (device < 0 || device >= n) return set_error(RT_ERR_INVALID_ARG, "rt_init: device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    g_device = device;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipFree(s->d_ttri), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
+    (void)hipFree(s->d_cache), (void)hipFree(s->d_spill);
+    delete s;
+}
+
+int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const float* hdr_map, const float* hdr_cache,
+                    int hdrW, int hdrH, rt_scene** out) {
+    if (!out) return set_error(RT_ERR_INVALID_ARG, "rt_scene_create: out is NULL");
+    *out = nullptr;
+    if (nT < 0 || nN < 0 || (nT > 0 && !tris) || (nN > 0 && !nodes))
+        return set_error(RT_ERR_INVALID_ARG, "rt_scene_create: bad triangle/node arguments");
+    if (nT >= (1 << 24)) return set_error(RT_ERR_INVALID_ARG, "rt_scene_create: %d triangles: fp32-encoded indices need < 2^24", nT);
+    if ((hdr_map || hdr_cache) && (hdrW <= 0 || hdrH <= 0 || (long long)hdrW * hdrH > (1ll << 28)))
+        return set_error(RT_ERR_INVALID_ARG, "rt_scene_create: bad HDR size %dx%d", hdrW, hdrH);
+    if (hdr_cache && !hdr_map) return set_error(RT_ERR_INVALID_ARG, "rt_scene_create: hdr_cache without hdr_map");
+    if (g_device < 0) {
+        const int rc = rt_init(0);
+        if (rc != RT_OK) return rc;
+    }
+
+    // ---- validate the BVH (root = node 1, f5:268) and number the internal nodes in pre-order -----------------
+    const NodeRec* N = (const NodeRec*)nodes;
+    std::vector<int> rec_of(nN > 0 ? nN : 0, -1);   // internal node -> record index
+    std::vector<int> entry(nN > 0 ? nN : 0, 0);     // node -> packed entry
+    std::vector<int> order;                        // internal nodes in record order
+    int max_depth = 0;
+    const bool has_root = nN >= 2;
+    if (has_root) {
+        std::vector<char> seen(nN, 0);
+        std::vector<std::pair<int, int>> stack;  // node, depth
+        stack.push_back({1, 0});
+        while (!stack.empty()) {
+            const int id = stack.back().first, depth = stack.back().second;
+            stack.pop_back();
+            if (id < 1 || id >= nN) return set_error(RT_ERR_BAD_BVH, "rt_scene_create: node index %d out of range [1,%d)", id, nN);
+            if (seen[id]) return set_error(RT_ERR_BAD_BVH, "rt_scene_create: node %d reachable twice (not a tree)", id);
+            seen[id] = 1;
+            if (depth > max_depth) max_depth = depth;
+            int l, r, n, index;
+            if (!f2i_checked(N[id].left, &l) || !f2i_checked(N[id].right, &r) || !f2i_checked(N[id].n, &n) ||
+                !f2i_checked(N[id].index, &index))
+                return set_error(RT_ERR_BAD_BVH, "rt_scene_create: node %d holds a non-integral index field", id);
+            if (n > 0) {  // leaf, f5:274
+                if (n > 128) return set_error(RT_ERR_BAD_BVH, "rt_scene_create: leaf %d holds %d triangles (max 128)", id, n);
+                if (index < 0 || (long long)index + n > nT)
+                    return set_error(RT_ERR_BAD_BVH, "rt_scene_create: leaf %d range [%d,%d) outside the %d triangles", id, index, index + n, nT);
+                entry[id] = pack_leaf(index, n);
+            } else {
+                if (l <= 0 || r <= 0)
+                    return set_error(RT_ERR_BAD_BVH, "rt_scene_create: internal node %d lacks a child (left=%d right=%d)", id, l, r);
+                rec_of[id] = (int)order.size();
+                entry[id] = rec_of[id];
+                order.push_back(id);
+                stack.push_back({r, depth + 1});  // left is numbered first (popped first)
+                stack.push_back({l, depth + 1});
+            }
+        }
+    }
+    const int need_stack = max_depth + 1;
+    if (need_stack > kMaxStack)
+        return set_error(RT_ERR_BAD_BVH, "rt_scene_create: tree depth %d overflows the reference's stack[256]", max_depth);
+
+    // ---- repack ------------------------------------------------------------------------------------------------
+    std::vector<float> rec(order.size() * 16, 0.0f);
+    for (size_t k = 0; k < order.size(); ++k) {
+        const NodeRec& nd = N[order[k]];
+        const int l = (int)nd.left, r = (int)nd.right;
+        float* q = &rec[k * 16];
+        q[0] = N[l].AA.x, q[1] = N[l].AA.y, q[2] = N[l].AA.z, q[3] = N[l].BB.x, q[4] = N[l].BB.y, q[5] = N[l].BB.z;
+        q[6] = N[r].AA.x, q[7] = N[r].AA.y, q[8] = N[r].AA.z, q[9] = N[r].BB.x, q[10] = N[r].BB.y, q[11] = N[r].BB.z;
+        memcpy(&q[12], &entry[l], 4);
+        memcpy(&q[13], &entry[r], 4);
+    }
+    std::vector<float> ttri((size_t)nT * 12);
+    for (int i = 0; i < nT; ++i) {
+        const TriRec& t = ((const TriRec*)tris)[i];
+        const vec3 Nn = normalize(cross(t.p2 - t.p1, t.p3 - t.p1));  // f5:180
+        float* q = &ttri[(size_t)i * 12];
+        q[0] = t.p1.x, q[1] = t.p1.y, q[2] = t.p1.z, q[3] = t.p2.x, q[4] = t.p2.y, q[5] = t.p2.z;
+        q[6] = t.p3.x, q[7] = t.p3.y, q[8] = t.p3.z, q[9] = Nn.x, q[10] = Nn.y, q[11] = Nn.z;
+    }
+
+    rt_scene* s = new rt_scene();
+    s->device = g_device;
+    s->nT = nT, s->nN = nN, s->max_stack = need_stack;
+    auto fail = [&](int rc) {
+        rt_scene_destroy(s);
+        return rc;
+    };
+#define HIPCHK_S(expr)                                                                                               \
+    do {                                                                                                             \
+        hipError_t e_ = (expr);                                                                                      \
+        if (e_ != hipSuccess) return fail(set_error(RT_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__)); \
+    } while (0)
+    HIPCHK_S(hipSetDevice(s->device));
+    if (nT > 0) {
+        HIPCHK_S(hipMalloc(&s->d_ttri, ttri.size() * 4));
+        HIPCHK_S(hipMemcpy(s->d_ttri, ttri.data(), ttri.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK_S(hipMalloc(&s->d_tris, (size_t)nT * 144));
+        HIPCHK_S(hipMemcpy(s->d_tris, tris, (size_t)nT * 144, hipMemcpyHostToDevice));
+    }
+    if (!rec.empty()) {
+        HIPCHK_S(hipMalloc(&s->d_nodes, rec.size() * 4));
+        HIPCHK_S(hipMemcpy(s->d_nodes, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+    }
+    const size_t npx = (size_t)(hdr_map ? hdrW : 0) * (size_t)(hdr_map ? hdrH : 0);
+    if (hdr_map) {
+        std::vector<float> tmp(npx * 4, 0.0f);
+        for (size_t i = 0; i < npx; ++i) tmp[i * 4] = hdr_map[i * 3], tmp[i * 4 + 1] = hdr_map[i * 3 + 1], tmp[i * 4 + 2] = hdr_map[i * 3 + 2];
+        HIPCHK_S(hipMalloc(&s->d_hdr, npx * 16));
+        HIPCHK_S(hipMemcpy(s->d_hdr, tmp.data(), npx * 16, hipMemcpyHostToDevice));
+        if (hdr_cache) {
+            for (size_t i = 0; i < npx; ++i) tmp[i * 4] = hdr_cache[i * 3], tmp[i * 4 + 1] = hdr_cache[i * 3 + 1], tmp[i * 4 + 2] = hdr_cache[i * 3 + 2];
+            HIPCHK_S(hipMalloc(&s->d_cache, npx * 16));
+            HIPCHK_S(hipMemcpy(s->d_cache, tmp.data(), npx * 16, hipMemcpyHostToDevice));
+        }
+    }
+#undef HIPCHK_S
+    s->dev.ttri = (const float4*)s->d_ttri;
+    s->dev.tris = (const float*)s->d_tris;
+    s->dev.nodes = (const float4*)s->d_nodes;
+    s->dev.hdr = (const float4*)s->d_hdr;
+    s->dev.cache = (const float4*)s->d_cache;
+    s->dev.hdrW = hdrW, s->dev.hdrH = hdrH;
+    s->dev.has_root = has_root ? 1 : 0;
+    s->dev.root_entry = has_root ? entry[1] : 0;
+    *out = s;
+    return RT_OK;
+}
+
+}  // extern "C"
+
+namespace rta {
+
+static int check_desc(const rt_scene* s, const rt_render_desc* d, const char* who) {
+    if (!s || !d) return set_error(RT_ERR_INVALID_ARG, "%s: NULL scene or descriptor", who);
+    if (d->width <= 0 || d->height <= 0 || (long long)d->width * d->height > (1ll << 30))
+        return set_error(RT_ERR_INVALID_ARG, "%s: bad image size %dx%d", who, d->width, d->height);
+    return RT_OK;
+}
+
+static int fill_params(rt_scene* s, const rt_render_desc* d, RenderParams* P, int* blocks) {
+    memset(P, 0, sizeof(*P));
+    P->sc = s->dev;
+    P->width = d->width, P->height = d->height;
+    P->accumulate = d->accumulate;
+    memcpy(P->eye, d->eye, sizeof(P->eye));
+    memcpy(P->cam, d->camera_rotate, sizeof(P->cam));
+    const int tilesx = (d->width + 15) / 16, tilesy = (d->height + 15) / 16;
+    *blocks = tilesx * tilesy;
+    if (s->max_stack > kLdsDepth) {  // deep tree: per-thread global spill beyond the LDS part of the stack
+        const size_t threads = (size_t)*blocks * kBlock;
+        const size_t bytes = threads * (size_t)(s->max_stack - kLdsDepth) * sizeof(int);
+        if (bytes > s->spill_bytes) {
+            (void)hipFree(s->d_spill);
+            s->d_spill = nullptr, s->spill_bytes = 0;
+            HIPCHK(hipMalloc((void**)&s->d_spill, bytes));
+            s->spill_bytes = bytes;
+        }
+        P->spill = s->d_spill;
+        P->spill_stride = (long long)threads;
+    }
+    return RT_OK;
+}
+
+template <bool STATS>
+static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_dev,
+                         unsigned long long* stats_dev, hipStream_t stream) {
+    int rc = check_desc(s, d, "rt_render");
+    if (rc != RT_OK) return rc;
+    if (!accum_dev) return set_error(RT_ERR_INVALID_ARG, "rt_render: accum is NULL");
+    if (frame_begin < 0 || frame_count < 0) return set_error(RT_ERR_INVALID_ARG, "rt_render: negative frame range");
+    if (d->mode != RT_MODE_CHAP3 && d->mode != RT_MODE_CHAP4 && d->mode != RT_MODE_CHAP5)
+        return set_error(RT_ERR_INVALID_ARG, "rt_render: unknown mode %d", d->mode);
+    if (d->accumulate != RT_ACCUM_RUNNING_MEAN && d->accumulate != RT_ACCUM_SUM)
+        return set_error(RT_ERR_INVALID_ARG, "rt_render: unknown accumulate mode %d", d->accumulate);
+    if (d->mode == RT_MODE_CHAP5 && !s->d_cache)
+        return set_error(RT_ERR_INVALID_ARG, "rt_render: mode 5 needs hdr_map and hdr_cache in the scene");
+    if (frame_count == 0) return RT_OK;
+    HIPCHK(hipSetDevice(s->device));
+    RenderParams P;
+    int blocks;
+    rc = fill_params(s, d, &P, &blocks);
+    if (rc != RT_OK) return rc;
+    P.max_bounce = d->max_bounce > 0 ? d->max_bounce : (d->mode == RT_MODE_CHAP5 ? 4 : 6);
+    P.frame_begin = frame_begin, P.frame_count = frame_count;
+    P.accum = accum_dev;
+    P.stats = stats_dev;
+    const bool spill = P.spill != nullptr;
+    TimedLaunch tl;
+    HIPCHK(hipEventCreate(&tl.a));
+    HIPCHK(hipEventCreate(&tl.b));
+    HIPCHK(hipEventRecord(tl.a, stream));
+#define LAUNCH(MODE_)                                                                                   \
+    do {                                                                                                \
+        if (spill)                                                                                      \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, true>), dim3(blocks), dim3(kBlock), 0, stream, P);  \
+        else                                                                                            \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, false>), dim3(blocks), dim3(kBlock), 0, stream, P); \
+    } while (0)
+    if (d->mode == RT_MODE_CHAP5)
+        LAUNCH(RT_MODE_CHAP5);
+    else if (d->mode == RT_MODE_CHAP4)
+        LAUNCH(RT_MODE_CHAP4);
+    else
+        LAUNCH(RT_MODE_CHAP3);
+#undef LAUNCH
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(tl.b, stream));
+    if (!STATS)
+        g_launches.push_back(tl);
+    else {
+        (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
+    }
+    return RT_OK;
+}
+
+}  // namespace rta
+
+extern "C" {
+
+int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_dev, void* stream) {
+    return launch_render<false>(s, d, frame_begin, frame_count, accum_dev, nullptr, (hipStream_t)stream);
+}
+
+int rt_render(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_host) {
+    int rc = check_desc(s, d, "rt_render");
+    if (rc != RT_OK) return rc;
+    if (!accum_host) return set_error(RT_ERR_INVALID_ARG, "rt_render: accum is NULL");
+    HIPCHK(hipSetDevice(s->device));
+    const size_t bytes = (size_t)d->width * d->height * 3 * sizeof(float);
+    float* dev = nullptr;
+    HIPCHK(hipMalloc((void**)&dev, bytes));
+    hipError_t e = hipMemcpy(dev, accum_host, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = rt_render_device(s, d, frame_begin, frame_count, dev, nullptr);
+        if (rc == RT_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(accum_host, dev, bytes, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(dev);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_render: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out) {
+    int rc = check_desc(s, d, "rt_render_stats");
+    if (rc != RT_OK) return rc;
+    if (!out) return set_error(RT_ERR_INVALID_ARG, "rt_render_stats: out is NULL");
+    HIPCHK(hipSetDevice(s->device));
+    const size_t bytes = (size_t)d->width * d->height * 3 * sizeof(float);
+    float* dev = nullptr;
+    unsigned long long* st = nullptr;
+    HIPCHK(hipMalloc((void**)&dev, bytes));
+    hipError_t e = hipMalloc((void**)&st, 6 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(dev, 0, bytes);
+    if (e == hipSuccess) e = hipMemset(st, 0, 6 * sizeof(unsigned long long));
+    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    if (e == hipSuccess) {
+        rc = launch_render<true>(s, d, frame_begin, frame_count, dev, st, nullptr);
+        if (rc == RT_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(dev), (void)hipFree(st);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_render_stats: %s", hipGetErrorString(e));
+    out->paths = h[0], out->rays = h[1], out->internal_nodes = h[2], out->leaf_nodes = h[3];
+    out->triangles_tested = h[4], out->hit_updates = h[5];
+    return RT_OK;
+}
+
+int rt_primary_hits_device(rt_scene* s, const rt_render_desc* d, int32_t* tri_dev, float* dist_dev, void* stream) {
+    int rc = check_desc(s, d, "rt_primary_hits");
+    if (rc != RT_OK) return rc;
+    if (!tri_dev || !dist_dev) return set_error(RT_ERR_INVALID_ARG, "rt_primary_hits: NULL output");
+    HIPCHK(hipSetDevice(s->device));
+    RenderParams P;
+    int blocks;
+    rc = fill_params(s, d, &P, &blocks);
+    if (rc != RT_OK) return rc;
+    P.hit_tri = tri_dev, P.hit_dist = dist_dev;
+    TimedLaunch tl;
+    HIPCHK(hipEventCreate(&tl.a));
+    HIPCHK(hipEventCreate(&tl.b));
+    HIPCHK(hipEventRecord(tl.a, (hipStream_t)stream));
+    if (P.spill)
+        hipLaunchKernelGGL((primary_kernel<false, true>), dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, P);
+    else
+        hipLaunchKernelGGL((primary_kernel<false, false>), dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, P);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(tl.b, (hipStream_t)stream));
+    g_launches.push_back(tl);
+    return RT_OK;
+}
+
+int rt_primary_hits(rt_scene* s, const rt_render_desc* d, int32_t* tri_host, float* dist_host) {
+    int rc = check_desc(s, d, "rt_primary_hits");
+    if (rc != RT_OK) return rc;
+    if (!tri_host || !dist_host) return set_error(RT_ERR_INVALID_ARG, "rt_primary_hits: NULL output");
+    HIPCHK(hipSetDevice(s->device));
+    const size_t n = (size_t)d->width * d->height;
+    int32_t* dt = nullptr;
+    float* dd = nullptr;
+    HIPCHK(hipMalloc((void**)&dt, n * 4));
+    hipError_t e = hipMalloc((void**)&dd, n * 4);
+    if (e == hipSuccess) {
+        rc = rt_primary_hits_device(s, d, dt, dd, nullptr);
+        if (rc == RT_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(tri_host, dt, n * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(dist_host, dd, n * 4, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(dt), (void)hipFree(dd);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_primary_hits: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_kernel_time_ms(float* avg_ms, int* launches, int reset) {
+    double total = 0;
+    int n = 0;
+    for (auto& tl : g_launches) {
+        float ms = 0;
+        if (hipEventSynchronize(tl.b) == hipSuccess && hipEventElapsedTime(&ms, tl.a, tl.b) == hipSuccess) {
+            total += ms;
+            ++n;
+        }
+    }
+    if (avg_ms) *avg_ms = n ? (float)(total / n) : 0.0f;
+    if (launches) *launches = n;
+    if (reset) {
+        for (auto& tl : g_launches) (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
+        g_launches.clear();
+    }
+    return RT_OK;
+}
+
+}  // extern "C"

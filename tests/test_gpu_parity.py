@@ -1,0 +1,227 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bars: primary-hit indices and distances bit-exact (integer/index work); rendered images bit-exact against the oracle
+run with the build's fixed fp32 transcendental sequences (every other operation is IEEE fp32 in the reference's
+order), and within a stated RMSE of the oracle run with libm transcendentals (the reference's GLSL built-ins are
+driver-defined, so that comparison is statistical).  The BRDF/MIS loop has no independent reference output
+(SURVEY §8c): these image tests are restatement-vs-kernel — parity unpinned by the reference itself.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ray_tracing_amd as rt
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _assert_images_equal(gpu, ora, what):
+    same = _bits(gpu) == _bits(ora)
+    both_nan = np.isnan(gpu) & np.isnan(ora)
+    bad = ~(same | both_nan)
+    assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} floats differ; first at {np.argwhere(bad)[:4].tolist()}"
+
+
+@pytest.mark.parametrize("r", [4.0, 1.7])
+def test_primary_hits_chap2_scene_bit_exact(scene_chap2, r):
+    tris, nodes = scene_chap2
+    sc = rt.Scene(tris, nodes)
+    W, H = 480, 270
+    eye = np.array([0, 0, r], np.float32)
+    d = rt.make_desc(W, H, eye=eye)
+    tri, dist = sc.primary_hits(d)
+    otri, odist = O.primary_hits(tris, nodes, W, H, eye, np.eye(4, dtype=np.float32).reshape(16))
+    assert (tri >= 0).sum() > 100
+    assert np.array_equal(tri, otri)
+    assert np.array_equal(_bits(dist), _bits(odist))
+
+
+def test_primary_hits_1080p_golden_count(scene_chap2):
+    """Full config-2 size: SURVEY §8c records 45 494 hits at eye=(0,0,4) from the reference source run here."""
+    tris, nodes = scene_chap2
+    sc = rt.Scene(tris, nodes)
+    d = rt.make_desc(1920, 1080, eye=(0, 0, 4))
+    tri, dist = sc.primary_hits(d)
+    assert int((tri >= 0).sum()) == 45494
+    assert np.all(dist[tri < 0] == np.float32(114514.0))
+    otri, odist = O.primary_hits(tris, nodes, 1920, 1080, np.array([0, 0, 4], np.float32), np.eye(4, dtype=np.float32).reshape(16))
+    assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
+
+
+def test_primary_hits_rotated_camera(scene_chap5):
+    tris, nodes = scene_chap5
+    sc = rt.Scene(tris, nodes)
+    eye, cam = rt.camera(35.0, 20.0, 3.0)
+    d = rt.make_desc(320, 200, eye=eye, camera_rotate=cam)
+    tri, dist = sc.primary_hits(d)
+    otri, odist = O.primary_hits(tris, nodes, 320, 200, eye, cam)
+    assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
+
+
+@pytest.mark.parametrize("mode", [3, 4, 5])
+def test_render_small_scene_bit_exact(scene_small, hdr_pair, mode):
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(20.0, 15.0, 3.5)
+    W, H, F = 96, 80, 6
+    d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam)
+    img = sc.render(d, 0, F)
+    ref, ost = O.render(tris, nodes, hdr, cache, W, H, mode, eye, cam, 0, F)
+    _assert_images_equal(img, ref, f"mode {mode}")
+    st = sc.render_stats(d, 0, F)
+    assert st == ost, (st, ost)
+
+
+@pytest.mark.parametrize("mode,scene", [(4, "scene_chap4"), (5, "scene_chap5")])
+def test_render_config_scenes_bit_exact_and_rmse(request, hdr_pair, mode, scene):
+    tris, nodes = request.getfixturevalue(scene)
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(0.0, 0.0, 4.0)  # the reference's start-up camera, c5:147-149
+    W, H, F = 160, 90, 4
+    d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam)
+    img = sc.render(d, 0, F)
+    ref, _ = O.render(tris, nodes, hdr, cache, W, H, mode, eye, cam, 0, F)
+    _assert_images_equal(img, ref, f"config mode {mode}")
+    # statistical check against libm transcendentals: tone-mapped RMSE <= 0.02, relative mean <= 1 %
+    lib, _ = O.render(tris, nodes, hdr, cache, W, H, mode, eye, cam, 0, F, use_libm=True)
+    a = rt.tonemap_rgb8(img).astype(np.float64) / 255.0
+    b = rt.tonemap_rgb8(lib).astype(np.float64) / 255.0
+    assert np.sqrt(np.mean((a - b) ** 2)) <= 0.02
+    assert abs(np.nanmean(img) - np.nanmean(lib)) <= 0.01 * abs(np.nanmean(lib)) + 1e-6
+
+
+def test_progressive_accumulation_continues_exactly(scene_small, hdr_pair):
+    """Frames 0..5 in one call == frames 0..2 then 3..5 with the accumulation buffer carried (lastFrame, f5:954-955)."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(10.0, 5.0, 3.0)
+    d = rt.make_desc(64, 48, mode=5, eye=eye, camera_rotate=cam)
+    one = sc.render(d, 0, 6)
+    two = sc.render(d, 0, 3)
+    two = sc.render(d, 3, 3, two)
+    _assert_images_equal(one, two, "split accumulation")
+
+
+def test_sum_mode_matches_oracle_and_mean(scene_small, hdr_pair):
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(0.0, 10.0, 3.0)
+    W, H, F = 64, 64, 8
+    d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam, accumulate=rt.RT_ACCUM_SUM)
+    s = sc.render(d, 0, F)
+    ref, _ = O.render(tris, nodes, hdr, cache, W, H, 5, eye, cam, 0, F, accumulate=1)
+    _assert_images_equal(s, ref, "sum mode")
+    d.accumulate = rt.RT_ACCUM_RUNNING_MEAN
+    mean = sc.render(d, 0, F)
+    ok = np.isfinite(mean)
+    assert np.allclose(s[ok] / F, mean[ok], rtol=2e-5, atol=1e-6)
+
+
+def test_empty_scene_is_all_environment(hdr_pair):
+    hdr, cache = hdr_pair
+    sc = rt.Scene(np.zeros((0, 36), np.float32), np.zeros((1, 12), np.float32), hdr, cache)
+    eye, cam = rt.camera(0, 0, 4)
+    d = rt.make_desc(40, 30, mode=5, eye=eye, camera_rotate=cam)
+    img = sc.render(d, 0, 2)
+    ref, _ = O.render(np.zeros((0, 36), np.float32), np.zeros((1, 12), np.float32), hdr, cache, 40, 30, 5, eye, cam, 0, 2)
+    _assert_images_equal(img, ref, "empty scene")
+    tri, dist = sc.primary_hits(d)
+    assert (tri == -1).all()
+
+
+def test_ragged_image_sizes(scene_small, hdr_pair):
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(0.0, 0.0, 3.0)
+    for (W, H) in ((1, 1), (17, 5), (33, 31)):
+        d = rt.make_desc(W, H, mode=4, eye=eye, camera_rotate=cam)
+        img = sc.render(d, 0, 2)
+        ref, _ = O.render(tris, nodes, hdr, cache, W, H, 4, eye, cam, 0, 2)
+        _assert_images_equal(img, ref, f"{W}x{H}")
+
+
+def test_single_leaf_root(hdr_pair):
+    """A BVH whose root is a leaf (<= 8 triangles): f5:274 handles it on the first pop."""
+    from ray_tracing_amd import scenes
+    hdr, cache = hdr_pair
+    m = rt.Mesh()
+    m.readObj(scenes._m("sphere.obj"), rt.Material(baseColor=(0.7, 0.2, 0.2), roughness=0.4),
+              rt.getTransformMatrix((0, 0, 0), (0, 0, 0), (2, 2, 2)), True)
+    tris = m.triangles()[:6].copy()
+    m2 = rt.Mesh()
+    m2.append(tris)
+    nodes = m2.buildBVHwithSAH(8)
+    assert nodes.shape[0] == 2 and nodes[1, 3] == 6
+    tris = m2.triangles()
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(0, 0, 3)
+    d = rt.make_desc(48, 48, mode=5, eye=eye, camera_rotate=cam)
+    img = sc.render(d, 0, 3)
+    ref, _ = O.render(tris, nodes, hdr, cache, 48, 48, 5, eye, cam, 0, 3)
+    _assert_images_equal(img, ref, "leaf root")
+
+
+def test_bad_bvh_is_rejected(scene_small):
+    tris, nodes = scene_small
+    bad = nodes.copy()
+    bad[1, 0] = 1.0  # root's left child = root -> cycle
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene(tris, bad)
+    assert e.value.code == -6
+    bad = nodes.copy()
+    leaf = int(np.argmax(nodes[1:, 3] > 0)) + 1
+    bad[leaf, 4] = float(tris.shape[0])  # leaf range outside the triangle array
+    with pytest.raises(rt.RtError):
+        rt.Scene(tris, bad)
+
+
+def test_deep_tree_spills_stack_exactly():
+    """A hand-built left-deep chain whose deep subtree is always the nearer child makes the traversal stack grow to
+    60 entries, past the 32 kept in LDS, so the global spill path is exercised."""
+    depth = 60
+    tris = np.zeros((depth + 1, 36), np.float32)
+    for k in range(depth + 1):
+        z = -1.0 + 0.01 * k  # higher index = nearer to the eye at z = +2
+        tris[k, :9] = np.array([[-0.5, -0.5, z], [0.5, -0.5, z], [0.0, 0.5, z]], np.float32).reshape(-1)
+        tris[k, 9:18] = np.tile([0, 0, 1], 3)
+        tris[k, 21:24] = 1.0
+        tris[k, 34] = 1.0
+
+    def box(lo, hi):
+        pts = tris[lo:hi, :9].reshape(-1, 3)
+        return pts.min(0), pts.max(0)
+
+    nodes = np.zeros((2 * depth + 2, 12), np.float32)
+    ids = [1 + 2 * i for i in range(depth)]
+    last_leaf = 1 + 2 * depth
+    for i in range(depth):
+        me, leaf = ids[i], ids[i] + 1
+        nxt = ids[i + 1] if i + 1 < depth else last_leaf
+        nodes[me, 0], nodes[me, 1] = nxt, leaf
+        nodes[me, 6:9], nodes[me, 9:12] = box(i, depth + 1)
+        nodes[leaf, 3], nodes[leaf, 4] = 1, i
+        nodes[leaf, 6:9], nodes[leaf, 9:12] = box(i, i + 1)
+    nodes[last_leaf, 3], nodes[last_leaf, 4] = 1, depth
+    nodes[last_leaf, 6:9], nodes[last_leaf, 9:12] = box(depth, depth + 1)
+    sc = rt.Scene(tris, nodes)
+    eye = np.array([0.0, 0.0, 2.0], np.float32)
+    d = rt.make_desc(64, 32, eye=eye)
+    tri, dist = sc.primary_hits(d)
+    otri, odist = O.primary_hits(tris, nodes, 64, 32, eye, np.eye(4, dtype=np.float32).reshape(16))
+    assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
+    assert (tri == depth).any()
+    hdr = np.full((4, 8, 3), 0.5, np.float32)
+    sc2 = rt.Scene(tris, nodes, hdr, None)
+    d4 = rt.make_desc(32, 32, mode=4, eye=eye)
+    img = sc2.render(d4, 0, 2)
+    ref, _ = O.render(tris, nodes, hdr, None, 32, 32, 4, eye, np.eye(4, dtype=np.float32).reshape(16), 0, 2)
+    _assert_images_equal(img, ref, "deep tree render")
