@@ -32,9 +32,10 @@ def main():
     ap.add_argument("--scene", default="chap5", choices=["chap5", "chap4", "small", "synthetic"])
     ap.add_argument("--synthetic-objects", type=int, default=64)
     ap.add_argument("--synthetic-subdiv", type=int, default=48)
+    ap.add_argument("--up-angle", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
-    ap.add_argument("--cpu-sample", default="480x270x4", help="WxHxSPP sample of the same workload for the CPU oracle")
+    ap.add_argument("--cpu-sample", default="960x540x8", help="WxHxSPP sample of the same workload for the CPU oracle")
     args = ap.parse_args()
 
     import numpy as np
@@ -67,7 +68,9 @@ def main():
         tris, nodes = scenes.synthetic_scene(args.synthetic_objects, args.synthetic_subdiv)
     hdr, cache = scenes.hdr_and_cache()
     scene = rt.Scene(tris, nodes, hdr, cache, device=local_rank)
-    eye, cam = rt.camera(0.0, 0.0, 4.0)  # the reference's start-up camera (c5:147-149)
+    # orbit camera of c5:716-720 at r = 4 (c5:149), raised 20 degrees: at the start-up upAngle = 0 the eye sits under the
+    # floor slab (y = 0.2) and sees only its underside, so the first thing a user does is drag the view up
+    eye, cam = rt.camera(0.0, args.up_angle, 4.0)
     W, H, spp = args.width, args.height, args.spp
     acc_mode = rt.RT_ACCUM_SUM if world > 1 else rt.RT_ACCUM_RUNNING_MEAN
     desc = rt.make_desc(W, H, mode=args.mode, eye=eye, camera_rotate=cam, accumulate=acc_mode)
@@ -120,7 +123,7 @@ def main():
         "dtype": "f32",
         "data": "reference's bundled scene + HDR (assets/); synthetic camera rays",
         "config": {"workload": f"path_tracing_5chap scene ({tris.shape[0]} triangles, {nodes.shape[0]} nodes), mode chap{args.mode}, "
-                               f"{W}x{H}, {spp} spp per step per GPU, maxBounce {4 if args.mode == 5 else 6}"
+                               f"{W}x{H}, orbit camera r=4 up={args.up_angle:g} deg, {spp} spp per step per GPU, maxBounce {4 if args.mode == 5 else 6}"
                    if args.scene == "chap5" else f"{args.scene} scene ({tris.shape[0]} triangles), mode chap{args.mode}, {W}x{H}, {spp} spp/step/GPU",
                    "parallelism": f"spp-split x{world}, scene replicated, 1 RCCL reduce per step" if world > 1 else "single GPU"},
     }

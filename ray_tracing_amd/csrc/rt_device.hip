@@ -172,6 +172,7 @@ __device__ __forceinline__ int hitBVH(const DevScene& sc, const LaneStack& stk, 
             if (STATS) st.leaves++;
             const int first = cur & 0x00ffffff;
             const int n = ((cur >> 24) & 0x7f) + 1;
+            float leaf_best = INF_;  // STATS only: hitArray restarts from INF in every leaf (f5:246)
             for (int i = first; i < first + n; ++i) {
                 const float4 a = sc.ttri[i * 3 + 0], b = sc.ttri[i * 3 + 1], c = sc.ttri[i * 3 + 2];
                 float t;
@@ -185,8 +186,11 @@ __device__ __forceinline__ int hitBVH(const DevScene& sc, const LaneStack& stk, 
                         better = (t < best) || (t == best && first > best_first);
                     else
                         better = t < best;
+                    if (STATS && t < leaf_best) {  // H = improvements inside hitArray (f5:250-253)
+                        st.updates++;
+                        leaf_best = t;
+                    }
                     if (better) {
-                        if (STATS) st.updates++;
                         best = t;
                         best_tri = i;
                         best_first = first;
