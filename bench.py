@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--up-angle", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
-    ap.add_argument("--cpu-sample", default="960x540x8", help="WxHxSPP sample of the same workload for the CPU oracle")
+    ap.add_argument("--cpu-sample", default="1920x1080x32", help="WxHxSPP sample of the same workload for the CPU oracle")
     args = ap.parse_args()
 
     import numpy as np

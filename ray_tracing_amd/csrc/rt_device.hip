@@ -312,7 +312,8 @@ __device__ __forceinline__ vec3 trace_sample(const RenderParams& P, const LaneSt
             const vec3 Lh = hdrDirection(ce.x, ce.y);
             if (dot(N, Lh) > 0.0f) {
                 float th;
-                const int occl = hitBVH<true, TIE_SHADER, STATS, SPILL>(sc, stk, hit.hitPoint, Lh, &th, st);
+                // statistics builds count the reference's full traversal (f5:866), so they do not stop at the first hit
+                const int occl = hitBVH<!STATS, TIE_SHADER, STATS, SPILL>(sc, stk, hit.hitPoint, Lh, &th, st);
                 if (occl < 0) {
                     const vec3 color = envColor<MODE>(sc, Lh);
                     const float pdf_light = envPdf(sc, Lh);
