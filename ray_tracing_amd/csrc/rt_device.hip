@@ -74,6 +74,7 @@ struct RenderParams {
     int* spill;            // global stack spill, [depth - kLdsDepth][thread]
     long long spill_stride;
     unsigned long long* stats;  // 6 counters (STATS builds)
+    int refill;            // lanes waiting for a handler that end the shared traversal loop
     int32_t* hit_tri;      // primary-hit query outputs
     float* hit_dist;
 };
@@ -277,109 +278,6 @@ __device__ __forceinline__ float envPdf(const DevScene& sc, vec3 L) {  // hdrPdf
     return hdrPdfConvert(c.z, w, sc.hdrW);
 }
 
-// ---- P1 / P1' / chap3: one pixel sample (fshader.fsh main() up to the frame blend) ------------------------------
-template <int MODE, bool STATS, bool SPILL>
-__device__ __forceinline__ vec3 trace_sample(const RenderParams& P, const LaneStack& stk, float pixx, float pixy,
-                                             unsigned frame, float cpu, float cpv, Stats& st) {
-    const DevScene& sc = P.sc;
-    unsigned seed = pixel_seed(pixx, pixy, P.width, P.height, frame);
-    const vec3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
-    const float aax = (rand01(seed) - 0.5f) / (float)P.width;
-    const float aay = (rand01(seed) - 0.5f) / (float)P.height;
-    const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
-    const float* m = P.cam;  // column-major: m[col*4+row]
-    vec3 dir;
-    dir.x = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
-    dir.y = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
-    dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
-    dir = normalize(dir);
-
-    float t;
-    int tri = hitBVH<false, TIE_SHADER, STATS, SPILL>(sc, stk, eye, dir, &t, st);
-    if (tri < 0) return envColor<MODE>(sc, dir);
-    Hit hit = finish_hit<MODE>(sc, eye, dir, tri, t);
-    Mat mat = load_material(sc, tri);
-    const vec3 Le0 = mat.emissive;
-
-    vec3 Lo = v3(0);
-    vec3 history = v3(1);
-    for (int bounce = 0; bounce < P.max_bounce; ++bounce) {
-        const vec3 V = -hit.viewDir;
-        const vec3 N = hit.normal;
-        if (MODE == RT_MODE_CHAP5) {  // f5:850-923
-            const float r1 = rand01(seed), r2 = rand01(seed);
-            const float4 ce = sc.cache[texel_index(r2, sc.hdrH) * sc.hdrW + texel_index(r1, sc.hdrW)];
-            const vec3 Lh = hdrDirection(ce.x, ce.y);
-            if (dot(N, Lh) > 0.0f) {
-                float th;
-                // statistics builds count the reference's full traversal (f5:866), so they do not stop at the first hit
-                const int occl = hitBVH<!STATS, TIE_SHADER, STATS, SPILL>(sc, stk, hit.hitPoint, Lh, &th, st);
-                if (occl < 0) {
-                    const vec3 color = envColor<MODE>(sc, Lh);
-                    const float pdf_light = envPdf(sc, Lh);
-                    float pdf_brdf;
-                    const vec3 f_r = disney_eval<false, true>(V, N, Lh, v3(0), v3(0), mat, &pdf_brdf);
-                    const float mis_weight = misMixWeight(pdf_light, pdf_brdf);
-                    Lo += mis_weight * history * color * f_r * dot(N, Lh) / pdf_light;
-                }
-            }
-            const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
-            const float su = sobol_dim(d_sobolV, bounce * 2, gray);
-            const float sv = sobol_dim(d_sobolV, bounce * 2 + 1, gray);
-            const float xi_1 = cp_rotate(su, cpu);
-            const float xi_2 = cp_rotate(sv, cpv);
-            const float xi_3 = rand01(seed);
-            const vec3 L = SampleBRDF(xi_1, xi_2, xi_3, V, N, mat);
-            const float NdotL = dot(N, L);
-            if (NdotL <= 0.0f) break;
-            tri = hitBVH<false, TIE_SHADER, STATS, SPILL>(sc, stk, hit.hitPoint, L, &t, st);
-            float pdf_brdf;
-            const vec3 f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
-            if (pdf_brdf <= 0.0f) break;
-            if (tri < 0) {
-                const vec3 color = envColor<MODE>(sc, L);
-                const float pdf_light = envPdf(sc, L);
-                const float mis_weight = misMixWeight(pdf_brdf, pdf_light);
-                Lo += mis_weight * history * color * NdotL * f_r / pdf_brdf;
-                break;
-            }
-            const Hit newhit = finish_hit<MODE>(sc, hit.hitPoint, L, tri, t);
-            mat = load_material(sc, tri);
-            Lo += history * mat.emissive * NdotL * f_r / pdf_brdf;
-            hit = newhit;
-            history *= NdotL * f_r / pdf_brdf;
-        } else {  // f4:505-541 (chap4) and f3:378-416 (chap3)
-            const vec3 L = toNormalHemisphere(SampleHemisphereRand(seed), N);
-            const float pdf = 1.0f / (2.0f * PI_);
-            const float cosine_i = fmax_(0.0f, dot(MODE == RT_MODE_CHAP4 ? N : L, MODE == RT_MODE_CHAP4 ? L : N));
-            vec3 f_r;
-            if (MODE == RT_MODE_CHAP4) {
-                vec3 tangent, bitangent;
-                getTagent(N, tangent, bitangent);
-                f_r = disney_eval<true, false>(V, N, L, tangent, bitangent, mat, nullptr);
-            } else {
-                f_r = mat.baseColor / PI_;
-            }
-            tri = hitBVH<false, TIE_SHADER, STATS, SPILL>(sc, stk, hit.hitPoint, L, &t, st);
-            if (tri < 0) {
-                const vec3 skyColor = envColor<MODE>(sc, L);
-                Lo += history * skyColor * f_r * cosine_i / pdf;
-                break;
-            }
-            const Hit newhit = finish_hit<MODE>(sc, hit.hitPoint, L, tri, t);
-            const Mat newmat = load_material(sc, tri);
-            if (MODE == RT_MODE_CHAP4)
-                Lo += history * newmat.emissive * cosine_i / pdf;  // f4:535: no f_r
-            else
-                Lo += history * newmat.emissive * f_r * cosine_i / pdf;  // f3:407
-            hit = newhit;
-            mat = newmat;
-            history *= f_r * cosine_i / pdf;
-        }
-    }
-    return Le0 + Lo;
-}
-
 __device__ __forceinline__ bool lane_pixel(const RenderParams& P, int* px, int* py) {
     // block = 16x16 pixels, wave w = 8x8 sub-tile (w&1, w>>1), lane l = (l&7, l>>3)
     const int tilesx = (P.width + 15) >> 4;
@@ -399,9 +297,24 @@ __device__ __forceinline__ void flush_stats(const RenderParams& P, const Stats& 
     }
 }
 
+// ---- the path loop as a per-lane state machine ----------------------------------------------------------------
+// fshader.fsh main() (f5:926-988) + pathTracingImportanceSampling (f5:850-923) / pathTracing (f4:505-541, f3:378-416),
+// cut at every hitBVH call.  A lane owns one pixel and walks its frames in order; between two hitBVH calls it runs one
+// of four "handlers".  All 64 lanes of a wave share ONE traversal loop, whatever frame, bounce or ray kind each lane is
+// in; a lane whose ray has finished parks until the ballot says enough lanes are waiting (or none is traversing), then
+// the wave runs the handlers once, each handler executed by all lanes that need it, and every parked lane re-enters the
+// traversal with its next ray (persistent lanes, ballot-driven refill).  Traversal itself is "while-while": all lanes
+// first walk internal nodes until each holds a leaf, then the leaves are scanned one triangle per step.  Node and leaf
+// visit order per ray is exactly the reference's (f5:259-311), so are the arithmetic and the RNG call order.
+enum LaneState { ST_NEW = 0, ST_TRAV = 1, ST_RAYDONE = 2, ST_DONE = 3 };
+enum RayKind { K_PRIMARY = 0, K_SHADOW = 1, K_BOUNCE = 2 };
+
+constexpr int kRefillLanes = 20;  // leave the traversal loop once this many lanes wait for a handler
+
 template <int MODE, bool STATS, bool SPILL>
 __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
     __shared__ int s_stack[kLdsDepth * kBlock];
+    const DevScene& sc = P.sc;
     int px, py;
     const bool active = lane_pixel(P, &px, &py);
     LaneStack stk;
@@ -410,24 +323,269 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
     stk.spill = SPILL ? (P.spill + ((long long)blockIdx.x * kBlock + threadIdx.x)) : nullptr;
     Stats st = {0, 0, 0, 0, 0};
     unsigned long long paths = 0;
-    if (active) {
-        // pix = interpolated quad position at the pixel centre (vshader.vsh:7-10), GL row order (row 0 = bottom)
-        const float pixx = -1.0f + 2.0f * ((float)px + 0.5f) / (float)P.width;
-        const float pixy = -1.0f + 2.0f * ((float)py + 0.5f) / (float)P.height;
-        float cpu = 0.0f, cpv = 0.0f;
-        if (MODE == RT_MODE_CHAP5) cp_shift(pixx, pixy, P.width, P.height, &cpu, &cpv);
-        float* out = P.accum + ((size_t)py * P.width + px) * 3;
-        vec3 acc = v3(out[0], out[1], out[2]);
-        for (int f = 0; f < P.frame_count; ++f) {
+
+    // per-pixel constants: pix = quad position at the pixel centre (vshader.vsh:7-10), GL row order (row 0 = bottom)
+    const float pixx = -1.0f + 2.0f * ((float)px + 0.5f) / (float)P.width;
+    const float pixy = -1.0f + 2.0f * ((float)py + 0.5f) / (float)P.height;
+    float cpu = 0.0f, cpv = 0.0f;
+    if (MODE == RT_MODE_CHAP5) cp_shift(pixx, pixy, P.width, P.height, &cpu, &cpv);
+    float* out = P.accum + ((size_t)(active ? py : 0) * P.width + (active ? px : 0)) * 3;
+    vec3 acc = active ? v3(out[0], out[1], out[2]) : v3(0);
+
+    // lane state
+    int state = active ? ST_NEW : ST_DONE;
+    int kind = K_PRIMARY;
+    int f = 0;                      // frames done
+    unsigned seed = 0;
+    int bounce = 0;
+    vec3 S = v3(0), d = v3(0, 0, 1), invdir = v3(0);  // ray in flight
+    int cur = 0, sp = 0, best_tri = -1;
+    float best = INF_;
+    vec3 hitP = v3(0), N = v3(0), V = v3(0);  // current surface point: hit.hitPoint, hit.normal, -hit.viewDir
+    int surf_tri = -1;              // triangle of the current surface point (material source)
+    int first_tri = -1;             // triangle of the primary hit (Le), -1 = primary miss
+    vec3 Lo = v3(0), history = v3(1);
+
+    for (;;) {
+        bool to_B = false, to_C = false, fin = false, emit = false;
+
+        // ---- handler D: the BRDF ray came back (f5:896-920; f4:525-538; f3:391-412) ------------------------------
+        if (state == ST_RAYDONE && kind == K_BOUNCE) {
+            const Mat mat = load_material(sc, surf_tri);
+            const vec3 L = d;
+            if (MODE == RT_MODE_CHAP5) {
+                const float NdotL = dot(N, L);
+                float pdf_brdf;
+                const vec3 f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
+                if (pdf_brdf <= 0.0f) {
+                    fin = true;
+                } else if (best_tri < 0) {
+                    const vec3 color = envColor<MODE>(sc, L);
+                    const float pdf_light = envPdf(sc, L);
+                    const float mis_weight = misMixWeight(pdf_brdf, pdf_light);
+                    Lo += mis_weight * history * color * NdotL * f_r / pdf_brdf;
+                    fin = true;
+                } else {
+                    const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
+                    const float* T = sc.tris + (size_t)best_tri * 36 + 18;
+                    const vec3 Le = v3(T[0], T[1], T[2]);
+                    Lo += history * Le * NdotL * f_r / pdf_brdf;
+                    history *= NdotL * f_r / pdf_brdf;
+                    hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
+                    bounce++;
+                    if (bounce < P.max_bounce) to_B = true; else fin = true;
+                }
+            } else {
+                const float pdf = 1.0f / (2.0f * PI_);
+                const float cosine_i = fmax_(0.0f, dot(N, L));
+                vec3 f_r;
+                if (MODE == RT_MODE_CHAP4) {
+                    vec3 tangent, bitangent;
+                    getTagent(N, tangent, bitangent);
+                    f_r = disney_eval<true, false>(V, N, L, tangent, bitangent, mat, nullptr);
+                } else {
+                    f_r = mat.baseColor / PI_;
+                }
+                if (best_tri < 0) {
+                    const vec3 skyColor = envColor<MODE>(sc, L);
+                    Lo += history * skyColor * f_r * cosine_i / pdf;
+                    fin = true;
+                } else {
+                    const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
+                    const float* T = sc.tris + (size_t)best_tri * 36 + 18;
+                    const vec3 Le = v3(T[0], T[1], T[2]);
+                    if (MODE == RT_MODE_CHAP4)
+                        Lo += history * Le * cosine_i / pdf;        // f4:535: no f_r
+                    else
+                        Lo += history * Le * f_r * cosine_i / pdf;  // f3:407
+                    history *= f_r * cosine_i / pdf;
+                    hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
+                    bounce++;
+                    if (bounce < P.max_bounce) to_B = true; else fin = true;
+                }
+            }
+        }
+
+        // ---- handler A: the primary ray came back (f5:940-951) ---------------------------------------------------
+        if (state == ST_RAYDONE && kind == K_PRIMARY) {
+            if (best_tri < 0) {
+                Lo = envColor<MODE>(sc, d);
+                first_tri = -1;
+                fin = true;
+            } else {
+                const Hit h = finish_hit<MODE>(sc, S, d, best_tri, best);
+                hitP = h.hitPoint, N = h.normal, V = -h.viewDir, surf_tri = best_tri;
+                first_tri = best_tri;
+                Lo = v3(0), history = v3(1), bounce = 0;
+                if (bounce < P.max_bounce) to_B = true; else fin = true;
+            }
+        }
+
+        // ---- handler B: start of a bounce (f5:856-866 env sample; chapters 3/4: the hemisphere sample) -----------
+        if (to_B) {
+            if (MODE == RT_MODE_CHAP5) {
+                const float r1 = rand01(seed), r2 = rand01(seed);
+                const float4 ce = sc.cache[texel_index(r2, sc.hdrH) * sc.hdrW + texel_index(r1, sc.hdrW)];
+                const vec3 Lh = hdrDirection(ce.x, ce.y);
+                if (dot(N, Lh) > 0.0f) {
+                    S = hitP, d = Lh, kind = K_SHADOW, emit = true;
+                } else {
+                    to_C = true;
+                }
+            } else {
+                const vec3 L = toNormalHemisphere(SampleHemisphereRand(seed), N);
+                S = hitP, d = L, kind = K_BOUNCE, emit = true;
+            }
+        }
+
+        // ---- handler C (chap5): the env-visibility ray came back (f5:869-881), then BRDF sampling (f5:883-895) ----
+        if (MODE == RT_MODE_CHAP5 && !emit && ((state == ST_RAYDONE && kind == K_SHADOW) || to_C)) {
+            const Mat mat = load_material(sc, surf_tri);
+            if (!to_C && best_tri < 0) {
+                const vec3 L = d;
+                const vec3 color = envColor<MODE>(sc, L);
+                const float pdf_light = envPdf(sc, L);
+                float pdf_brdf;
+                const vec3 f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
+                const float mis_weight = misMixWeight(pdf_light, pdf_brdf);
+                Lo += mis_weight * history * color * f_r * dot(N, L) / pdf_light;
+            }
             const unsigned frame = (unsigned)(P.frame_begin + f);
-            const vec3 color = trace_sample<MODE, STATS, SPILL>(P, stk, pixx, pixy, frame, cpu, cpv, st);
+            const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
+            const float su = sobol_dim(d_sobolV, bounce * 2, gray);
+            const float sv = sobol_dim(d_sobolV, bounce * 2 + 1, gray);
+            const float xi_1 = cp_rotate(su, cpu);
+            const float xi_2 = cp_rotate(sv, cpv);
+            const float xi_3 = rand01(seed);
+            const vec3 L = SampleBRDF(xi_1, xi_2, xi_3, V, N, mat);
+            if (dot(N, L) <= 0.0f) {
+                fin = true;
+            } else {
+                S = hitP, d = L, kind = K_BOUNCE, emit = true;
+            }
+        }
+
+        // ---- end of a sample: frame blend (f5:954-955) -----------------------------------------------------------
+        if (fin) {
+            vec3 color = Lo;
+            if (first_tri >= 0) {
+                const float* T = sc.tris + (size_t)first_tri * 36 + 18;
+                color = v3(T[0], T[1], T[2]) + Lo;  // Le + Li, f5:950
+            }
+            const unsigned frame = (unsigned)(P.frame_begin + f);
             if (P.accumulate == RT_ACCUM_SUM)
                 acc = acc + color;
             else
-                acc = mix3(acc, color, 1.0f / (float)(int)(frame + 1u));  // f5:955
+                acc = mix3(acc, color, 1.0f / (float)(int)(frame + 1u));
             if (STATS) paths++;
+            f++;
+            state = ST_NEW;
         }
-        out[0] = acc.x, out[1] = acc.y, out[2] = acc.z;
+
+        // ---- next sample: seed, jitter, camera ray (f5:320-323, 932-937) -----------------------------------------
+        if (state == ST_NEW) {
+            if (f >= P.frame_count) {
+                state = ST_DONE;
+                out[0] = acc.x, out[1] = acc.y, out[2] = acc.z;
+            } else {
+                const unsigned frame = (unsigned)(P.frame_begin + f);
+                seed = pixel_seed(pixx, pixy, P.width, P.height, frame);
+                const float aax = (rand01(seed) - 0.5f) / (float)P.width;
+                const float aay = (rand01(seed) - 0.5f) / (float)P.height;
+                const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
+                const float* m = P.cam;  // column-major: m[col*4+row]
+                vec3 dir;
+                dir.x = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
+                dir.y = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
+                dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
+                S = v3(P.eye[0], P.eye[1], P.eye[2]), d = normalize(dir), kind = K_PRIMARY, emit = true;
+            }
+        }
+
+        // ---- hitBVH prologue (f5:260-268) -------------------------------------------------------------------------
+        if (emit) {
+            if (STATS) st.rays++;
+            best = INF_, best_tri = -1, sp = 0, cur = sc.root_entry;
+            invdir = v3(1.0f) / d;
+            state = sc.has_root ? ST_TRAV : ST_RAYDONE;
+        }
+        if (!__any(state != ST_DONE)) break;
+        if (!sc.has_root) continue;
+
+        // ---- shared traversal loop --------------------------------------------------------------------------------
+        for (;;) {
+            // internal nodes: every traversing lane walks down until it holds a leaf (or its ray ends)
+            for (;;) {
+                const bool in = (state == ST_TRAV) && (cur >= 0);
+                if (!__any(in)) break;
+                if (in) {
+                    if (STATS) st.internal++;
+                    const float4 q0 = sc.nodes[cur * 4 + 0], q1 = sc.nodes[cur * 4 + 1], q2 = sc.nodes[cur * 4 + 2],
+                                 q3 = sc.nodes[cur * 4 + 3];
+                    const float d1 = hitAABB(S, invdir, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y));
+                    const float d2 = hitAABB(S, invdir, v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w));
+                    const int le = __float_as_int(q3.x), re = __float_as_int(q3.y);
+                    if (d1 > 0.0f && d2 > 0.0f) {
+                        if (d1 < d2) {  // left first
+                            stack_push<SPILL>(stk, sp++, re);
+                            cur = le;
+                        } else {        // right first (ties included)
+                            stack_push<SPILL>(stk, sp++, le);
+                            cur = re;
+                        }
+                    } else if (d1 > 0.0f) {
+                        cur = le;
+                    } else if (d2 > 0.0f) {
+                        cur = re;
+                    } else if (sp == 0) {
+                        state = ST_RAYDONE;
+                    } else {
+                        cur = stack_pop<SPILL>(stk, --sp);
+                    }
+                }
+            }
+            // leaves: one triangle per step and lane (hitArray, f5:243-256)
+            bool leaf = (state == ST_TRAV);  // cur < 0 here
+            int i = cur & 0x00ffffff;
+            const int end = i + ((cur >> 24) & 0x7f) + 1;
+            float leaf_best = INF_;
+            if (STATS && leaf) st.leaves++;
+            for (;;) {
+                const bool go = leaf && (i < end);
+                if (!__any(go)) break;
+                if (go) {
+                    const float4 a = sc.ttri[i * 3 + 0], b = sc.ttri[i * 3 + 1], c = sc.ttri[i * 3 + 2];
+                    float t;
+                    if (STATS) st.tris++;
+                    if (hitTriangleT(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), S, d, &t)) {
+                        if (STATS && t < leaf_best) {
+                            st.updates++;
+                            leaf_best = t;
+                        }
+                        if (t < best) {  // strict <: the first visited candidate keeps a tie (f5:250, 278)
+                            best = t;
+                            best_tri = i;
+                            // an env-visibility ray only needs isHit (f5:869); statistics builds count the full walk
+                            if (!STATS && kind == K_SHADOW) {
+                                state = ST_RAYDONE;
+                                leaf = false;
+                            }
+                        }
+                    }
+                    i++;
+                }
+            }
+            if (leaf) {
+                if (sp == 0)
+                    state = ST_RAYDONE;
+                else
+                    cur = stack_pop<SPILL>(stk, --sp);
+            }
+            // ballot-driven refill: hand the parked lanes to the handlers once enough of them wait
+            const int n_trav = __popcll(__ballot(state == ST_TRAV));
+            const int n_wait = __popcll(__ballot(state == ST_RAYDONE));
+            if (n_trav == 0 || n_wait >= P.refill) break;
+        }
     }
     if (STATS) flush_stats(P, st, paths);
 }
@@ -660,6 +818,8 @@ static int fill_params(rt_scene* s, const rt_render_desc* d, RenderParams* P, in
     memcpy(P->cam, d->camera_rotate, sizeof(P->cam));
     const int tilesx = (d->width + 15) / 16, tilesy = (d->height + 15) / 16;
     *blocks = tilesx * tilesy;
+    P->refill = kRefillLanes;
+    if (const char* e = getenv("RT_AMD_REFILL")) P->refill = atoi(e) > 0 ? atoi(e) : kRefillLanes;  // tuning knob
     if (s->max_stack > kLdsDepth) {  // deep tree: per-thread global spill beyond the LDS part of the stack
         const size_t threads = (size_t)*blocks * kBlock;
         const size_t bytes = threads * (size_t)(s->max_stack - kLdsDepth) * sizeof(int);
