@@ -297,19 +297,39 @@ __device__ __forceinline__ void flush_stats(const RenderParams& P, const Stats& 
     }
 }
 
-// ---- the path loop as a per-lane state machine ----------------------------------------------------------------
+// ---- the path loop as a per-lane state machine with a wave-level scheduler ------------------------------------
 // fshader.fsh main() (f5:926-988) + pathTracingImportanceSampling (f5:850-923) / pathTracing (f4:505-541, f3:378-416),
-// cut at every hitBVH call.  A lane owns one pixel and walks its frames in order; between two hitBVH calls it runs one
-// of four "handlers".  All 64 lanes of a wave share ONE traversal loop, whatever frame, bounce or ray kind each lane is
-// in; a lane whose ray has finished parks until the ballot says enough lanes are waiting (or none is traversing), then
-// the wave runs the handlers once, each handler executed by all lanes that need it, and every parked lane re-enters the
-// traversal with its next ray (persistent lanes, ballot-driven refill).  Traversal itself is "while-while": all lanes
-// first walk internal nodes until each holds a leaf, then the leaves are scanned one triangle per step.  Node and leaf
-// visit order per ray is exactly the reference's (f5:259-311), so are the arithmetic and the RNG call order.
-enum LaneState { ST_NEW = 0, ST_TRAV = 1, ST_RAYDONE = 2, ST_DONE = 3 };
-enum RayKind { K_PRIMARY = 0, K_SHADOW = 1, K_BOUNCE = 2 };
+// cut at every hitBVH call.  A lane owns one pixel and walks its frames in order.  At any moment a lane waits for exactly
+// one "op":
+//   OP_INT   one internal-node step of hitBVH (two child boxes, f5:282-307)
+//   OP_LEAF  one triangle of hitArray (f5:247-254)
+//   OP_A     the primary ray came back   (f5:940-951)
+//   OP_C     the env-visibility ray came back / was skipped, then BRDF sampling (f5:869-895)      [chap5 only]
+//   OP_D     the BRDF ray came back      (f5:896-920; f4:525-538; f3:391-412)
+// Each pass of the wave's single loop ballots the five populations, picks ONE op and executes it for every lane waiting
+// on it (persistent lanes; the ballot decides what runs, and parked lanes are refilled with their next ray by the
+// handler that serves them).  Cheap traversal steps keep running while lanes accumulate at the expensive handlers, so
+// each handler pass is executed by many lanes, whatever frame, bounce or ray kind each lane is in.  Per lane the sequence
+// of nodes, leaves, triangles, arithmetic and RNG calls is exactly the reference's.
+enum LaneOp { OP_INT = 0, OP_LEAF = 1, OP_A = 2, OP_C = 3, OP_D = 4, OP_DONE = 5 };
+enum RayKind { K_PRIMARY = 0, K_SHADOW = 1, K_BOUNCE = 2, K_NONE = 3 };
 
-constexpr int kRefillLanes = 20;  // leave the traversal loop once this many lanes wait for a handler
+constexpr int kHandlerLanes = 12;  // run a handler once this many lanes wait for it (or nothing is traversing)
+
+// hitAABB (f5:225-238) with hardware min/max.  Equal to the ternary form whenever no operand is NaN (the results are
+// only compared, so the sign of a zero does not matter); rays that can produce NaN (a zero/NaN direction component or a
+// non-finite origin) take the exact form instead (`slow`).
+__device__ __forceinline__ float hitAABB_fast(vec3 S, vec3 invdir, vec3 AA, vec3 BB) {
+    const vec3 f = (BB - S) * invdir;
+    const vec3 n = (AA - S) * invdir;
+    const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fmaxf(f.y, n.y)), __builtin_fmaxf(f.z, n.z));
+    const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(f.x, n.x), __builtin_fminf(f.y, n.y)), __builtin_fminf(f.z, n.z));
+    return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+}
+__device__ __forceinline__ bool finite3(vec3 v) {
+    const float inf = __builtin_inff();
+    return (fabs_(v.x) < inf) && (fabs_(v.y) < inf) && (fabs_(v.z) < inf);
+}
 
 template <int MODE, bool STATS, bool SPILL>
 __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
@@ -323,6 +343,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
     stk.spill = SPILL ? (P.spill + ((long long)blockIdx.x * kBlock + threadIdx.x)) : nullptr;
     Stats st = {0, 0, 0, 0, 0};
     unsigned long long paths = 0;
+    unsigned dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // STATS builds: passes / active-lane sums per op
 
     // per-pixel constants: pix = quad position at the pixel centre (vshader.vsh:7-10), GL row order (row 0 = bottom)
     const float pixx = -1.0f + 2.0f * ((float)px + 0.5f) / (float)P.width;
@@ -333,261 +354,282 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
     vec3 acc = active ? v3(out[0], out[1], out[2]) : v3(0);
 
     // lane state
-    int state = active ? ST_NEW : ST_DONE;
+    int op = OP_DONE;
     int kind = K_PRIMARY;
     int f = 0;                      // frames done
     unsigned seed = 0;
     int bounce = 0;
     vec3 S = v3(0), d = v3(0, 0, 1), invdir = v3(0);  // ray in flight
-    int cur = 0, sp = 0, best_tri = -1;
+    bool slow = false;              // this ray needs the NaN-exact box test
+    int cur = 0, sp = 0, best_tri = -1, ti = 0;        // ti: next triangle of the leaf in `cur`
     float best = INF_;
+    float leaf_best = INF_;         // STATS only
     vec3 hitP = v3(0), N = v3(0), V = v3(0);  // current surface point: hit.hitPoint, hit.normal, -hit.viewDir
     int surf_tri = -1;              // triangle of the current surface point (material source)
     int first_tri = -1;             // triangle of the primary hit (Le), -1 = primary miss
     vec3 Lo = v3(0), history = v3(1);
 
+    bool need_new = active;         // start the first sample in the prologue pass
+    int pick = OP_A;                // the prologue runs the handler tail once with no handler body
     for (;;) {
-        bool to_B = false, to_C = false, fin = false, emit = false;
-
-        // ---- handler D: the BRDF ray came back (f5:896-920; f4:525-538; f3:391-412) ------------------------------
-        if (state == ST_RAYDONE && kind == K_BOUNCE) {
-            const Mat mat = load_material(sc, surf_tri);
-            const vec3 L = d;
-            if (MODE == RT_MODE_CHAP5) {
-                const float NdotL = dot(N, L);
-                float pdf_brdf;
-                const vec3 f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
-                if (pdf_brdf <= 0.0f) {
+        if (pick >= OP_A) {
+            bool to_B = false, fin = false, emit = false;
+            // ---- OP_D: the BRDF ray came back --------------------------------------------------------------------
+            if (pick == OP_D && op == OP_D) {
+                const Mat mat = load_material(sc, surf_tri);
+                const vec3 L = d;
+                if (MODE == RT_MODE_CHAP5) {
+                    const float NdotL = dot(N, L);
+                    float pdf_brdf;
+                    const vec3 f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
+                    if (pdf_brdf <= 0.0f) {
+                        fin = true;
+                    } else if (best_tri < 0) {
+                        const vec3 color = envColor<MODE>(sc, L);
+                        const float pdf_light = envPdf(sc, L);
+                        const float mis_weight = misMixWeight(pdf_brdf, pdf_light);
+                        Lo += mis_weight * history * color * NdotL * f_r / pdf_brdf;
+                        fin = true;
+                    } else {
+                        const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
+                        const float* T = sc.tris + (size_t)best_tri * 36 + 18;
+                        const vec3 Le = v3(T[0], T[1], T[2]);
+                        Lo += history * Le * NdotL * f_r / pdf_brdf;
+                        history *= NdotL * f_r / pdf_brdf;
+                        hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
+                        bounce++;
+                        if (bounce < P.max_bounce) to_B = true; else fin = true;
+                    }
+                } else {
+                    const float pdf = 1.0f / (2.0f * PI_);
+                    const float cosine_i = fmax_(0.0f, dot(N, L));
+                    vec3 f_r;
+                    if (MODE == RT_MODE_CHAP4) {
+                        vec3 tangent, bitangent;
+                        getTagent(N, tangent, bitangent);
+                        f_r = disney_eval<true, false>(V, N, L, tangent, bitangent, mat, nullptr);
+                    } else {
+                        f_r = mat.baseColor / PI_;
+                    }
+                    if (best_tri < 0) {
+                        const vec3 skyColor = envColor<MODE>(sc, L);
+                        Lo += history * skyColor * f_r * cosine_i / pdf;
+                        fin = true;
+                    } else {
+                        const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
+                        const float* T = sc.tris + (size_t)best_tri * 36 + 18;
+                        const vec3 Le = v3(T[0], T[1], T[2]);
+                        if (MODE == RT_MODE_CHAP4)
+                            Lo += history * Le * cosine_i / pdf;        // f4:535: no f_r
+                        else
+                            Lo += history * Le * f_r * cosine_i / pdf;  // f3:407
+                        history *= f_r * cosine_i / pdf;
+                        hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
+                        bounce++;
+                        if (bounce < P.max_bounce) to_B = true; else fin = true;
+                    }
+                }
+            }
+            // ---- OP_A: the primary ray came back -----------------------------------------------------------------
+            if (pick == OP_A && op == OP_A) {
+                if (best_tri < 0) {
+                    Lo = envColor<MODE>(sc, d);
+                    first_tri = -1;
                     fin = true;
-                } else if (best_tri < 0) {
+                } else {
+                    const Hit h = finish_hit<MODE>(sc, S, d, best_tri, best);
+                    hitP = h.hitPoint, N = h.normal, V = -h.viewDir, surf_tri = best_tri;
+                    first_tri = best_tri;
+                    Lo = v3(0), history = v3(1), bounce = 0;
+                    if (bounce < P.max_bounce) to_B = true; else fin = true;
+                }
+            }
+            // ---- OP_C (chap5): env-visibility result (f5:869-881), then BRDF sampling (f5:883-895) ---------------
+            if (MODE == RT_MODE_CHAP5 && pick == OP_C && op == OP_C) {
+                const Mat mat = load_material(sc, surf_tri);
+                if (kind == K_SHADOW && best_tri < 0) {
+                    const vec3 L = d;
                     const vec3 color = envColor<MODE>(sc, L);
                     const float pdf_light = envPdf(sc, L);
-                    const float mis_weight = misMixWeight(pdf_brdf, pdf_light);
-                    Lo += mis_weight * history * color * NdotL * f_r / pdf_brdf;
-                    fin = true;
-                } else {
-                    const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
-                    const float* T = sc.tris + (size_t)best_tri * 36 + 18;
-                    const vec3 Le = v3(T[0], T[1], T[2]);
-                    Lo += history * Le * NdotL * f_r / pdf_brdf;
-                    history *= NdotL * f_r / pdf_brdf;
-                    hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
-                    bounce++;
-                    if (bounce < P.max_bounce) to_B = true; else fin = true;
+                    float pdf_brdf;
+                    const vec3 f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
+                    const float mis_weight = misMixWeight(pdf_light, pdf_brdf);
+                    Lo += mis_weight * history * color * f_r * dot(N, L) / pdf_light;
                 }
-            } else {
-                const float pdf = 1.0f / (2.0f * PI_);
-                const float cosine_i = fmax_(0.0f, dot(N, L));
-                vec3 f_r;
-                if (MODE == RT_MODE_CHAP4) {
-                    vec3 tangent, bitangent;
-                    getTagent(N, tangent, bitangent);
-                    f_r = disney_eval<true, false>(V, N, L, tangent, bitangent, mat, nullptr);
-                } else {
-                    f_r = mat.baseColor / PI_;
-                }
-                if (best_tri < 0) {
-                    const vec3 skyColor = envColor<MODE>(sc, L);
-                    Lo += history * skyColor * f_r * cosine_i / pdf;
-                    fin = true;
-                } else {
-                    const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
-                    const float* T = sc.tris + (size_t)best_tri * 36 + 18;
-                    const vec3 Le = v3(T[0], T[1], T[2]);
-                    if (MODE == RT_MODE_CHAP4)
-                        Lo += history * Le * cosine_i / pdf;        // f4:535: no f_r
-                    else
-                        Lo += history * Le * f_r * cosine_i / pdf;  // f3:407
-                    history *= f_r * cosine_i / pdf;
-                    hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
-                    bounce++;
-                    if (bounce < P.max_bounce) to_B = true; else fin = true;
-                }
-            }
-        }
-
-        // ---- handler A: the primary ray came back (f5:940-951) ---------------------------------------------------
-        if (state == ST_RAYDONE && kind == K_PRIMARY) {
-            if (best_tri < 0) {
-                Lo = envColor<MODE>(sc, d);
-                first_tri = -1;
-                fin = true;
-            } else {
-                const Hit h = finish_hit<MODE>(sc, S, d, best_tri, best);
-                hitP = h.hitPoint, N = h.normal, V = -h.viewDir, surf_tri = best_tri;
-                first_tri = best_tri;
-                Lo = v3(0), history = v3(1), bounce = 0;
-                if (bounce < P.max_bounce) to_B = true; else fin = true;
-            }
-        }
-
-        // ---- handler B: start of a bounce (f5:856-866 env sample; chapters 3/4: the hemisphere sample) -----------
-        if (to_B) {
-            if (MODE == RT_MODE_CHAP5) {
-                const float r1 = rand01(seed), r2 = rand01(seed);
-                const float4 ce = sc.cache[texel_index(r2, sc.hdrH) * sc.hdrW + texel_index(r1, sc.hdrW)];
-                const vec3 Lh = hdrDirection(ce.x, ce.y);
-                if (dot(N, Lh) > 0.0f) {
-                    S = hitP, d = Lh, kind = K_SHADOW, emit = true;
-                } else {
-                    to_C = true;
-                }
-            } else {
-                const vec3 L = toNormalHemisphere(SampleHemisphereRand(seed), N);
-                S = hitP, d = L, kind = K_BOUNCE, emit = true;
-            }
-        }
-
-        // ---- handler C (chap5): the env-visibility ray came back (f5:869-881), then BRDF sampling (f5:883-895) ----
-        if (MODE == RT_MODE_CHAP5 && !emit && ((state == ST_RAYDONE && kind == K_SHADOW) || to_C)) {
-            const Mat mat = load_material(sc, surf_tri);
-            if (!to_C && best_tri < 0) {
-                const vec3 L = d;
-                const vec3 color = envColor<MODE>(sc, L);
-                const float pdf_light = envPdf(sc, L);
-                float pdf_brdf;
-                const vec3 f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
-                const float mis_weight = misMixWeight(pdf_light, pdf_brdf);
-                Lo += mis_weight * history * color * f_r * dot(N, L) / pdf_light;
-            }
-            const unsigned frame = (unsigned)(P.frame_begin + f);
-            const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
-            const float su = sobol_dim(d_sobolV, bounce * 2, gray);
-            const float sv = sobol_dim(d_sobolV, bounce * 2 + 1, gray);
-            const float xi_1 = cp_rotate(su, cpu);
-            const float xi_2 = cp_rotate(sv, cpv);
-            const float xi_3 = rand01(seed);
-            const vec3 L = SampleBRDF(xi_1, xi_2, xi_3, V, N, mat);
-            if (dot(N, L) <= 0.0f) {
-                fin = true;
-            } else {
-                S = hitP, d = L, kind = K_BOUNCE, emit = true;
-            }
-        }
-
-        // ---- end of a sample: frame blend (f5:954-955) -----------------------------------------------------------
-        if (fin) {
-            vec3 color = Lo;
-            if (first_tri >= 0) {
-                const float* T = sc.tris + (size_t)first_tri * 36 + 18;
-                color = v3(T[0], T[1], T[2]) + Lo;  // Le + Li, f5:950
-            }
-            const unsigned frame = (unsigned)(P.frame_begin + f);
-            if (P.accumulate == RT_ACCUM_SUM)
-                acc = acc + color;
-            else
-                acc = mix3(acc, color, 1.0f / (float)(int)(frame + 1u));
-            if (STATS) paths++;
-            f++;
-            state = ST_NEW;
-        }
-
-        // ---- next sample: seed, jitter, camera ray (f5:320-323, 932-937) -----------------------------------------
-        if (state == ST_NEW) {
-            if (f >= P.frame_count) {
-                state = ST_DONE;
-                out[0] = acc.x, out[1] = acc.y, out[2] = acc.z;
-            } else {
                 const unsigned frame = (unsigned)(P.frame_begin + f);
-                seed = pixel_seed(pixx, pixy, P.width, P.height, frame);
-                const float aax = (rand01(seed) - 0.5f) / (float)P.width;
-                const float aay = (rand01(seed) - 0.5f) / (float)P.height;
-                const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
-                const float* m = P.cam;  // column-major: m[col*4+row]
-                vec3 dir;
-                dir.x = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
-                dir.y = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
-                dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
-                S = v3(P.eye[0], P.eye[1], P.eye[2]), d = normalize(dir), kind = K_PRIMARY, emit = true;
+                const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
+                const float su = sobol_dim(d_sobolV, bounce * 2, gray);
+                const float sv = sobol_dim(d_sobolV, bounce * 2 + 1, gray);
+                const float xi_1 = cp_rotate(su, cpu);
+                const float xi_2 = cp_rotate(sv, cpv);
+                const float xi_3 = rand01(seed);
+                const vec3 L = SampleBRDF(xi_1, xi_2, xi_3, V, N, mat);
+                if (dot(N, L) <= 0.0f) {
+                    fin = true;
+                } else {
+                    S = hitP, d = L, kind = K_BOUNCE, emit = true;
+                }
             }
-        }
-
-        // ---- hitBVH prologue (f5:260-268) -------------------------------------------------------------------------
-        if (emit) {
-            if (STATS) st.rays++;
-            best = INF_, best_tri = -1, sp = 0, cur = sc.root_entry;
-            invdir = v3(1.0f) / d;
-            state = sc.has_root ? ST_TRAV : ST_RAYDONE;
-        }
-        if (!__any(state != ST_DONE)) break;
-        if (!sc.has_root) continue;
-
-        // ---- shared traversal loop --------------------------------------------------------------------------------
-        for (;;) {
-            // internal nodes: every traversing lane walks down until it holds a leaf (or its ray ends)
-            for (;;) {
-                const bool in = (state == ST_TRAV) && (cur >= 0);
-                if (!__any(in)) break;
-                if (in) {
-                    if (STATS) st.internal++;
-                    const float4 q0 = sc.nodes[cur * 4 + 0], q1 = sc.nodes[cur * 4 + 1], q2 = sc.nodes[cur * 4 + 2],
-                                 q3 = sc.nodes[cur * 4 + 3];
-                    const float d1 = hitAABB(S, invdir, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y));
-                    const float d2 = hitAABB(S, invdir, v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w));
-                    const int le = __float_as_int(q3.x), re = __float_as_int(q3.y);
-                    if (d1 > 0.0f && d2 > 0.0f) {
-                        if (d1 < d2) {  // left first
-                            stack_push<SPILL>(stk, sp++, re);
-                            cur = le;
-                        } else {        // right first (ties included)
-                            stack_push<SPILL>(stk, sp++, le);
-                            cur = re;
-                        }
-                    } else if (d1 > 0.0f) {
+            // ---- start of a bounce (f5:856-866 env sample; chapters 3/4: the hemisphere sample) ------------------
+            if (to_B) {
+                if (MODE == RT_MODE_CHAP5) {
+                    const float r1 = rand01(seed), r2 = rand01(seed);
+                    const float4 ce = sc.cache[texel_index(r2, sc.hdrH) * sc.hdrW + texel_index(r1, sc.hdrW)];
+                    const vec3 Lh = hdrDirection(ce.x, ce.y);
+                    if (dot(N, Lh) > 0.0f) {
+                        S = hitP, d = Lh, kind = K_SHADOW, emit = true;
+                    } else {
+                        kind = K_NONE, op = OP_C;  // no visibility ray: straight to BRDF sampling
+                    }
+                } else {
+                    const vec3 L = toNormalHemisphere(SampleHemisphereRand(seed), N);
+                    S = hitP, d = L, kind = K_BOUNCE, emit = true;
+                }
+            }
+            // ---- end of a sample: frame blend (f5:954-955) -------------------------------------------------------
+            if (fin) {
+                vec3 color = Lo;
+                if (first_tri >= 0) {
+                    const float* T = sc.tris + (size_t)first_tri * 36 + 18;
+                    color = v3(T[0], T[1], T[2]) + Lo;  // Le + Li, f5:950
+                }
+                const unsigned frame = (unsigned)(P.frame_begin + f);
+                if (P.accumulate == RT_ACCUM_SUM)
+                    acc = acc + color;
+                else
+                    acc = mix3(acc, color, 1.0f / (float)(int)(frame + 1u));
+                if (STATS) paths++;
+                f++;
+                need_new = true;
+            }
+            // ---- next sample: seed, jitter, camera ray (f5:320-323, 932-937) -------------------------------------
+            if (need_new) {
+                need_new = false;
+                if (f >= P.frame_count) {
+                    op = OP_DONE;
+                    out[0] = acc.x, out[1] = acc.y, out[2] = acc.z;
+                } else {
+                    const unsigned frame = (unsigned)(P.frame_begin + f);
+                    seed = pixel_seed(pixx, pixy, P.width, P.height, frame);
+                    const float aax = (rand01(seed) - 0.5f) / (float)P.width;
+                    const float aay = (rand01(seed) - 0.5f) / (float)P.height;
+                    const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
+                    const float* m = P.cam;  // column-major: m[col*4+row]
+                    vec3 dir;
+                    dir.x = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
+                    dir.y = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
+                    dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
+                    S = v3(P.eye[0], P.eye[1], P.eye[2]), d = normalize(dir), kind = K_PRIMARY, emit = true;
+                }
+            }
+            // ---- hitBVH prologue (f5:260-268) --------------------------------------------------------------------
+            if (emit) {
+                if (STATS) st.rays++;
+                best = INF_, best_tri = -1, sp = 0, cur = sc.root_entry;
+                invdir = v3(1.0f) / d;
+                slow = !(finite3(invdir) && finite3(S));
+                if (!sc.has_root) {
+                    op = (kind == K_PRIMARY) ? OP_A : ((kind == K_SHADOW) ? OP_C : OP_D);
+                } else if (cur >= 0) {
+                    op = OP_INT;
+                } else {
+                    op = OP_LEAF, ti = cur & 0x00ffffff, leaf_best = INF_;
+                    if (STATS) st.leaves++;
+                }
+            }
+        } else if (pick == OP_INT) {
+            // ---- one internal node (f5:282-307) ------------------------------------------------------------------
+            if (op == OP_INT) {
+                if (STATS) st.internal++;
+                const float4 q0 = sc.nodes[cur * 4 + 0], q1 = sc.nodes[cur * 4 + 1], q2 = sc.nodes[cur * 4 + 2],
+                             q3 = sc.nodes[cur * 4 + 3];
+                const vec3 lAA = v3(q0.x, q0.y, q0.z), lBB = v3(q0.w, q1.x, q1.y);
+                const vec3 rAA = v3(q1.z, q1.w, q2.x), rBB = v3(q2.y, q2.z, q2.w);
+                float d1 = hitAABB_fast(S, invdir, lAA, lBB);
+                float d2 = hitAABB_fast(S, invdir, rAA, rBB);
+                if (slow) {
+                    d1 = hitAABB(S, invdir, lAA, lBB);
+                    d2 = hitAABB(S, invdir, rAA, rBB);
+                }
+                const int le = __float_as_int(q3.x), re = __float_as_int(q3.y);
+                bool popped = false;
+                if (d1 > 0.0f && d2 > 0.0f) {
+                    if (d1 < d2) {  // left first
+                        stack_push<SPILL>(stk, sp++, re);
                         cur = le;
-                    } else if (d2 > 0.0f) {
+                    } else {        // right first (ties included)
+                        stack_push<SPILL>(stk, sp++, le);
                         cur = re;
-                    } else if (sp == 0) {
-                        state = ST_RAYDONE;
+                    }
+                } else if (d1 > 0.0f) {
+                    cur = le;
+                } else if (d2 > 0.0f) {
+                    cur = re;
+                } else if (sp == 0) {
+                    op = (kind == K_PRIMARY) ? OP_A : ((kind == K_SHADOW) ? OP_C : OP_D);
+                    popped = true;
+                } else {
+                    cur = stack_pop<SPILL>(stk, --sp);
+                }
+                if (!popped && cur < 0) {
+                    op = OP_LEAF, ti = cur & 0x00ffffff, leaf_best = INF_;
+                    if (STATS) st.leaves++;
+                }
+            }
+        } else {
+            // ---- one triangle of the leaf in `cur` (hitArray, f5:243-256) ----------------------------------------
+            if (op == OP_LEAF) {
+                const int end = (cur & 0x00ffffff) + ((cur >> 24) & 0x7f) + 1;
+                const float4 a = sc.ttri[ti * 3 + 0], b = sc.ttri[ti * 3 + 1], c = sc.ttri[ti * 3 + 2];
+                float t;
+                bool done = false;
+                if (STATS) st.tris++;
+                if (hitTriangleT(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), S, d, &t)) {
+                    if (STATS && t < leaf_best) {
+                        st.updates++;
+                        leaf_best = t;
+                    }
+                    if (t < best) {  // strict <: the first visited candidate keeps a tie (f5:250, 278)
+                        best = t;
+                        best_tri = ti;
+                        // an env-visibility ray only needs isHit (f5:869); statistics builds count the full walk
+                        if (!STATS && kind == K_SHADOW) done = true;
+                    }
+                }
+                ti++;
+                if (!done && ti >= end) {
+                    if (sp == 0) {
+                        done = true;
                     } else {
                         cur = stack_pop<SPILL>(stk, --sp);
-                    }
-                }
-            }
-            // leaves: one triangle per step and lane (hitArray, f5:243-256)
-            bool leaf = (state == ST_TRAV);  // cur < 0 here
-            int i = cur & 0x00ffffff;
-            const int end = i + ((cur >> 24) & 0x7f) + 1;
-            float leaf_best = INF_;
-            if (STATS && leaf) st.leaves++;
-            for (;;) {
-                const bool go = leaf && (i < end);
-                if (!__any(go)) break;
-                if (go) {
-                    const float4 a = sc.ttri[i * 3 + 0], b = sc.ttri[i * 3 + 1], c = sc.ttri[i * 3 + 2];
-                    float t;
-                    if (STATS) st.tris++;
-                    if (hitTriangleT(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), S, d, &t)) {
-                        if (STATS && t < leaf_best) {
-                            st.updates++;
-                            leaf_best = t;
-                        }
-                        if (t < best) {  // strict <: the first visited candidate keeps a tie (f5:250, 278)
-                            best = t;
-                            best_tri = i;
-                            // an env-visibility ray only needs isHit (f5:869); statistics builds count the full walk
-                            if (!STATS && kind == K_SHADOW) {
-                                state = ST_RAYDONE;
-                                leaf = false;
-                            }
+                        if (cur >= 0) {
+                            op = OP_INT;
+                        } else {
+                            ti = cur & 0x00ffffff, leaf_best = INF_;
+                            if (STATS) st.leaves++;
                         }
                     }
-                    i++;
                 }
+                if (done) op = (kind == K_PRIMARY) ? OP_A : ((kind == K_SHADOW) ? OP_C : OP_D);
             }
-            if (leaf) {
-                if (sp == 0)
-                    state = ST_RAYDONE;
-                else
-                    cur = stack_pop<SPILL>(stk, --sp);
-            }
-            // ballot-driven refill: hand the parked lanes to the handlers once enough of them wait
-            const int n_trav = __popcll(__ballot(state == ST_TRAV));
-            const int n_wait = __popcll(__ballot(state == ST_RAYDONE));
-            if (n_trav == 0 || n_wait >= P.refill) break;
         }
+
+        // ---- scheduler: ballot the populations, pick the next op ---------------------------------------------------
+        const int nI = __popcll(__ballot(op == OP_INT)), nL = __popcll(__ballot(op == OP_LEAF));
+        const int nA = __popcll(__ballot(op == OP_A)), nC = __popcll(__ballot(op == OP_C)), nD = __popcll(__ballot(op == OP_D));
+        if ((nI | nL | nA | nC | nD) == 0) break;
+        int hb = OP_A, hn = nA;
+        if (nC > hn) hb = OP_C, hn = nC;
+        if (nD > hn) hb = OP_D, hn = nD;
+        const int tb = (nL > nI) ? OP_LEAF : OP_INT, tn = (nL > nI) ? nL : nI;
+        pick = (tn == 0 || hn >= P.refill) ? hb : tb;
+        if (STATS && (threadIdx.x & 63) == 0) dg[2 * pick]++, dg[2 * pick + 1] += (pick >= OP_A) ? hn : tn;
     }
-    if (STATS) flush_stats(P, st, paths);
+    if (STATS) {
+        flush_stats(P, st, paths);
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 12; ++k) atomicAdd(&P.stats[6 + k], (unsigned long long)dg[k]);
+    }
 }
 
 // config 2: un-jittered camera rays, chapter-2 closest hit (c2:490-513)
@@ -818,8 +860,8 @@ static int fill_params(rt_scene* s, const rt_render_desc* d, RenderParams* P, in
     memcpy(P->cam, d->camera_rotate, sizeof(P->cam));
     const int tilesx = (d->width + 15) / 16, tilesy = (d->height + 15) / 16;
     *blocks = tilesx * tilesy;
-    P->refill = kRefillLanes;
-    if (const char* e = getenv("RT_AMD_REFILL")) P->refill = atoi(e) > 0 ? atoi(e) : kRefillLanes;  // tuning knob
+    P->refill = kHandlerLanes;
+    if (const char* e = getenv("RT_AMD_REFILL")) P->refill = atoi(e) > 0 ? atoi(e) : kHandlerLanes;  // tuning knob
     if (s->max_stack > kLdsDepth) {  // deep tree: per-thread global spill beyond the LDS part of the stack
         const size_t threads = (size_t)*blocks * kBlock;
         const size_t bytes = threads * (size_t)(s->max_stack - kLdsDepth) * sizeof(int);
@@ -926,10 +968,10 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     float* dev = nullptr;
     unsigned long long* st = nullptr;
     HIPCHK(hipMalloc((void**)&dev, bytes));
-    hipError_t e = hipMalloc((void**)&st, 6 * sizeof(unsigned long long));
+    hipError_t e = hipMalloc((void**)&st, 18 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(dev, 0, bytes);
-    if (e == hipSuccess) e = hipMemset(st, 0, 6 * sizeof(unsigned long long));
-    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemset(st, 0, 18 * sizeof(unsigned long long));
+    unsigned long long h[18] = {0};
     if (e == hipSuccess) {
         rc = launch_render<true>(s, d, frame_begin, frame_count, dev, st, nullptr);
         if (rc == RT_OK) {
@@ -940,6 +982,11 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     (void)hipFree(dev), (void)hipFree(st);
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_render_stats: %s", hipGetErrorString(e));
+    if (getenv("RT_AMD_DIAG")) {
+        static const char* nm[6] = {"OP_INT", "OP_LEAF", "OP_A(primary)", "OP_C(shadow)", "OP_D(bounce)", "-"};
+        for (int k = 0; k < 5; ++k)
+            fprintf(stderr, "[rt diag] %-18s wave passes %llu, mean active lanes %.1f\n", nm[k], h[6 + 2 * k], h[6 + 2 * k] ? (double)h[7 + 2 * k] / (double)h[6 + 2 * k] : 0.0);
+    }
     out->paths = h[0], out->rays = h[1], out->internal_nodes = h[2], out->leaf_nodes = h[3];
     out->triangles_tested = h[4], out->hit_updates = h[5];
     return RT_OK;
