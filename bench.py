@@ -56,7 +56,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import ray_tracing_amd as rt
-    from ray_tracing_amd import scenes
+    from ray_tracing_amd import parallel, scenes
 
     if args.scene == "chap5":
         tris, nodes = scenes.chap5_scene()
@@ -80,12 +80,12 @@ def main():
 
     def step(i):
         # rank r of `world` owns frames [ (i*world + r)*spp, +spp ): disjoint frameCounter ranges (seed f5:320-323)
-        fb = (i * world + rank) * spp
+        fb, fc = parallel.frame_range(i, rank, world, spp)
         if world > 1:
             accum.zero_()
-        scene.render_device(desc, fb, spp, accum.data_ptr(), stream)
+        scene.render_device(desc, fb, fc, accum.data_ptr(), stream)
         if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # one RCCL reduce per step over xGMI
+            parallel.reduce_sum(accum, dist, dst=0)  # one RCCL reduce per step over xGMI
 
     def fence():
         torch.cuda.synchronize(dev)

@@ -1,0 +1,335 @@
+"""CPU suite (-m "not gpu"): the oracle against the reference-derived known answers and the committed golden vectors,
+the product's host scene layer against the oracle (bit-exact), and the C ABI surface.  No device compute here."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ray_tracing_amd as rt
+from ray_tracing_amd import parallel, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "oracle_golden.npz"), allow_pickle=False)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C ABI surface
+# ---------------------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ray_tracing_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    lib = C.CDLL(rt.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(rt.Material) == 72          # texels 6..11 of Triangle_encoded
+    assert C.sizeof(rt.RenderDesc) == 5 * 4 + 3 * 4 + 16 * 4
+    assert C.sizeof(rt.TraceStats) == 48
+
+
+def test_errors_are_codes_not_aborts(tmp_path):
+    m = rt.Mesh()
+    with pytest.raises(rt.RtError) as e:
+        m.readObj(str(tmp_path / "missing.obj"), rt.Material(), np.eye(4, dtype=np.float32).reshape(16), True)
+    assert e.value.code == -2 and "cannot open" in str(e.value)
+    with pytest.raises(rt.RtError) as e:
+        rt.loadHDR(str(tmp_path / "missing.hdr"))
+    assert e.value.code == -2
+    bad = tmp_path / "bad.hdr"
+    bad.write_bytes(b"not a radiance file at all")
+    with pytest.raises(rt.RtError) as e:
+        rt.loadHDR(str(bad))
+    assert e.value.code == -3
+    with pytest.raises(rt.RtError):
+        rt.lib().rt_bvh_build  # exists
+        rt._check(rt.lib().rt_bvh_build(None, 8, 1, None, None))
+
+
+def test_device_entry_points_fail_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    tris, nodes = scenes.small_scene()
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene(tris, nodes)
+    assert e.value.code in (-5, -4)  # no device: there is no CPU fallback for the path loop
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reference-derived known answers (values printed by the reference source run in this container)
+# ---------------------------------------------------------------------------------------------------------------
+def test_scene_counts_match_reference(scene_chap2, scene_chap4, scene_chap5):
+    for (tris, nodes), exp in ((scene_chap2, (4970, 1741 + 1, 871)), (scene_chap4, (20480, 6898, 3449)), (scene_chap5, (19070, 6680, 3340))):
+        assert tris.shape[0] == exp[0]
+        assert nodes.shape[0] == exp[1]           # incl. the dummy node 0 (c5:835-843); chap2 has none (pointer tree)
+        assert int((nodes[1:, 3] > 0).sum()) == exp[2]
+        assert nodes[1:, 3].max() <= 8
+
+
+def test_chap2_known_answer_ray(scene_chap2):
+    """c2:605-609: ray (0,0,1) -> normalize(0.1,-0.1,-0.7) hits triangle 2054 at distance 0.76238."""
+    tris, nodes = scene_chap2
+    tri, dist = O.hit_one(tris, nodes, [0, 0, 1], [0.1, -0.1, -0.7])
+    assert tri == 2054
+    assert abs(dist - 0.76238) < 5e-6
+
+
+def test_chap2_1080p_hit_count_and_golden_map(scene_chap2):
+    tris, nodes = scene_chap2
+    tri, dist = O.primary_hits(tris, nodes, 1920, 1080, np.array([0, 0, 4], np.float32), np.eye(4, dtype=np.float32).reshape(16))
+    assert int((tri >= 0).sum()) == 45494
+    assert sha(tri) == str(GOLD["chap2_hits_1080p_sha"]) and sha(dist) == str(GOLD["chap2_dist_1080p_sha"])
+    assert np.array_equal(tri[4::8, 4::8], GOLD["chap2_hits_sub"])
+
+
+def test_hdr_and_cache_known_answers(hdr_pair):
+    hdr, cache = hdr_pair
+    assert hdr.shape == (512, 1024, 3)             # "-Y 512 +X 1024", not 4k
+    assert float(hdr.max()) == 21.0 and abs(float(hdr.mean()) - 0.30) < 0.01
+    assert abs(float(cache.reshape(-1)[23]) - 5.94006e-07) < 1e-12   # the value c5:910 prints
+    assert abs(float(cache[..., 2].astype(np.float64).sum()) - 1.0) < 1e-3   # sum of pdf = 1
+    assert cache[..., 0].min() >= 0 and cache[..., 0].max() <= 1.0 and cache[..., 1].max() <= 1.0
+    assert sha(hdr) == str(GOLD["hdr_sha"]) and sha(cache) == str(GOLD["cache_sha"])
+
+
+def test_sah_inf_cost_quirk_root_split(scene_chap5):
+    """Cost starts at INF = 114514 (c5:500): the chap5 root (area*count = 1.8e7) keeps the x-median split 9535 | 9535."""
+    tris, nodes = scene_chap5
+
+    def count(i):
+        n = nodes[i]
+        return int(n[3]) if n[3] > 0 else count(int(n[0])) + count(int(n[1]))
+    root = nodes[1]
+    assert count(int(root[0])) == 9535 and count(int(root[1])) == 9535
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# product host layer == oracle restatement, bit for bit
+# ---------------------------------------------------------------------------------------------------------------
+def _oracle_chap5():
+    A = rt.ASSETS
+    om = O.Mesh()
+    m = rt.Material(baseColor=(1.0, 0.84, 0.0), roughness=0.6, metallic=1.0, specular=0.8, clearcoat=0.2, clearcoatGloss=0.2)
+    om.read_obj(A + "/models/nanosuit.obj", m.as_array(), O.transform_matrix([0, 0, 0], [-0.8, 0.2, 0], [3, 3, 3]), True)
+    m.baseColor[:] = [1, 1, 1]
+    m.roughness, m.clearcoat, m.metallic, m.clearcoatGloss = 0.05, 0.2, 0.0, 1.0
+    om.read_obj(A + "/models/quad.obj", m.as_array(), O.transform_matrix([0, 0, 0], [0, 0.2, 0], [18.83, 0.01, 18.83]), False)
+    nodes = om.build(8, True)
+    return om.triangles(), nodes
+
+
+def test_host_chap5_scene_equals_oracle(scene_chap5):
+    tris, nodes = scene_chap5
+    ot, on = _oracle_chap5()
+    assert np.array_equal(bits(tris), bits(ot))
+    assert np.array_equal(bits(nodes[1:]), bits(on[1:]))   # node 0 is the dummy (its index field is uninitialised in the reference)
+    assert sha(tris) == str(GOLD["chap5_tris_sha"]) and sha(nodes[1:]) == str(GOLD["chap5_nodes_sha"])
+
+
+def test_host_chap2_scene_equals_oracle(scene_chap2):
+    tris, nodes = scene_chap2
+    om = O.Mesh()
+    om.read_obj_chap2(rt.ASSETS + "/models/Stanford Bunny.obj", 5.0, 0.5)
+    om.read_obj_chap2(rt.ASSETS + "/models_chap2/quad.obj", 1.0, 0.0)
+    on = om.build(8, True)
+    assert np.array_equal(bits(tris), bits(om.triangles())) and np.array_equal(bits(nodes[1:]), bits(on[1:]))
+    assert sha(tris) == str(GOLD["chap2_tris_sha"]) and sha(nodes[1:]) == str(GOLD["chap2_nodes_sha"])
+
+
+@pytest.mark.parametrize("sah", [True, False])
+@pytest.mark.parametrize("leaf_n", [1, 3, 8, 64])
+def test_bvh_builders_equal_oracle_on_tie_heavy_input(sah, leaf_n):
+    """Axis-aligned duplicated geometry = many comparator ties: the proxy sort must reproduce std::sort on structs."""
+    pm, om = rt.Mesh(), O.Mesh()
+    mat = rt.Material(baseColor=(0.5, 0.5, 0.5))
+    for k in range(5):
+        tr = rt.getTransformMatrix((0, 0, 0), (0.5 * (k % 2), 0.25 * k, 0), (1.0, 0.5, 1.0))
+        pm.readObj(scenes._m("quad.obj"), mat, tr, False)
+        om.read_obj(scenes._m("quad.obj"), mat.as_array(), O.transform_matrix((0, 0, 0), (0.5 * (k % 2), 0.25 * k, 0), (1.0, 0.5, 1.0)), False)
+    pm.readObj(scenes._m("sphere.obj"), mat, rt.getTransformMatrix((0, 0, 0), (0, 0, 0), (1, 1, 1)), True)
+    om.read_obj(scenes._m("sphere.obj"), mat.as_array(), O.transform_matrix((0, 0, 0), (0, 0, 0), (1, 1, 1)), True)
+    pn = pm.buildBVHwithSAH(leaf_n) if sah else pm.buildBVH(leaf_n)
+    on = om.build(leaf_n, sah)
+    assert np.array_equal(bits(pm.triangles()), bits(om.triangles()))
+    assert np.array_equal(bits(pn[1:]), bits(on[1:]))
+
+
+def test_empty_and_tiny_meshes():
+    m = rt.Mesh()
+    nodes = m.buildBVHwithSAH(8)
+    assert nodes.shape == (1, 12) and len(m) == 0          # only the dummy node: no root
+    m.readObj(scenes._m("quad.obj"), rt.Material(), rt.getTransformMatrix((0, 0, 0), (0, 0, 0), (1, 1, 1)), False)
+    one = rt.Mesh()
+    one.append(m.triangles()[:1])
+    n1 = one.buildBVHwithSAH(8)
+    assert n1.shape == (2, 12) and n1[1, 3] == 1 and n1[1, 4] == 0
+
+
+def test_transform_camera_hdr_equal_oracle(hdr_pair):
+    for args in (((0, 0, 0), (-0.8, 0.2, 0), (3, 3, 3)), ((10, 20, 30), (1, 2, 3), (2, 3, 4)), ((90, 0, 45), (0, 0, 0), (1, 1, 1))):
+        assert np.array_equal(bits(rt.getTransformMatrix(*args)), bits(O.transform_matrix(*args)))
+    for cam in ((0, 0, 4), (30, 20, 4), (-75, 89, 2.5), (170, -89, 6)):
+        e, c = rt.camera(*cam)
+        oe, oc = O.camera(*cam)
+        assert np.array_equal(bits(e), bits(oe)) and np.array_equal(bits(c), bits(oc))
+    e, c = rt.camera(0, 0, 4)
+    assert np.allclose(e, [0, 0, 4]) and np.allclose(c.reshape(4, 4).T, np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4], [0, 0, 0, 1]]), atol=1e-6)
+    hdr, cache = hdr_pair
+    oh = O.hdr_load(scenes.HDR_PATH)
+    assert np.array_equal(bits(hdr), bits(oh))
+    assert np.array_equal(bits(cache), bits(O.hdr_cache(oh)))
+
+
+def test_hdr_loader_old_rle_and_flat_files(tmp_path):
+    """hdr:161-191 old-style scanlines (width < 8 forces oldDecrunch) incl. a run-length repeat."""
+    w, h = 4, 2
+    px = [bytes([128, 64, 32, 129]), bytes([1, 1, 1, 2]), bytes([10, 20, 30, 128])]  # pixel, repeat x2, pixel
+    row = b"".join(px)
+    f = tmp_path / "t.hdr"
+    f.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 4\n" + row + row)
+    a = rt.loadHDR(str(f))
+    b = O.hdr_load(str(f))
+    assert a.shape == (2, 4, 3) and np.array_equal(bits(a), bits(b))
+    assert np.allclose(a[0, 0], [128 / 256 * 2, 64 / 256 * 2, 32 / 256 * 2])
+    assert np.array_equal(a[0, 1], a[0, 0]) and np.array_equal(a[0, 2], a[0, 0])
+    assert np.allclose(a[0, 3], [10 / 256, 20 / 256, 30 / 256])
+
+
+def test_tonemap_equals_oracle_and_png_equals_reference_svpng(tmp_path):
+    rng = np.random.RandomState(0)
+    img = (rng.rand(37, 53, 3).astype(np.float32) ** 3) * 8.0
+    img[0, 0] = [np.nan, -1.0, 1e9]
+    a, b = rt.tonemap_rgb8(img), O.tonemap_rgb8(img)
+    assert np.array_equal(a, b)
+    p = str(tmp_path / "a.png")
+    rt.write_png(p, a)
+    data = open(p, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), a)
+    if os.path.exists(O.REF_SVPNG_PATH):  # the reference's own svpng.inc, compiled where it lies (oracle/_ref)
+        ref = C.CDLL(O.REF_SVPNG_PATH)
+        q = str(tmp_path / "b.png")
+        assert ref.ref_svpng_write(q.encode(), 53, 37, a.ctypes.data_as(C.c_void_p), 0) == 0
+        assert open(q, "rb").read() == data
+        rgba = np.concatenate([a, np.full((37, 53, 1), 200, np.uint8)], -1)
+        rt.write_png(p, rgba)
+        assert ref.ref_svpng_write(q.encode(), 53, 37, rgba.ctypes.data_as(C.c_void_p), 1) == 0
+        assert open(q, "rb").read() == open(p, "rb").read()
+    with pytest.raises(rt.RtError):
+        rt.write_png(p, np.zeros((2, 30000, 3), np.uint8))   # row longer than one stored deflate block (svpng limit)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# oracle internals: RNG, Sobol, fixed transcendental sequences
+# ---------------------------------------------------------------------------------------------------------------
+def test_wang_hash_and_sobol_known_answers():
+    def wang(s):
+        s = ((s ^ 61) ^ (s >> 16)) & 0xFFFFFFFF
+        s = (s * 9) & 0xFFFFFFFF
+        s ^= s >> 4
+        s = (s * 0x27d4eb2d) & 0xFFFFFFFF
+        s ^= s >> 15
+        return s
+    for s0 in (1, 12345, 0xFFFFFFFF, (7 * 1973 + 9 * 9277 + 3 * 26699) | 1):
+        s = C.c_uint32(s0)
+        exp = s0
+        for _ in range(4):
+            exp = wang(exp)
+            assert O.raw.orc_wang_hash(C.byref(s)) == exp and s.value == exp
+    # V[0] = 2^31 (f5:339): sobol(0, gray(1)) = 0.5; dimension 0 is the radical inverse in base 2
+    assert O.raw.orc_sobol(0, 1 ^ (1 >> 1)) == 0.5
+    for i in range(1, 64):
+        g = i ^ (i >> 1)
+        x = O.raw.orc_sobol(0, g)
+        assert 0.0 <= x <= 1.0
+    vals = sorted(O.raw.orc_sobol(1, i ^ (i >> 1)) for i in range(16))
+    assert np.allclose(vals, np.arange(16) / 16.0, atol=1e-6)   # a (0,4,1)-net in base 2
+
+
+def test_fixed_transcendentals_track_libm():
+    rng = np.random.RandomState(1)
+
+    def ulps(got, ref):
+        ref32 = np.float32(ref)
+        return np.abs(np.float64(got) - ref) / np.maximum(np.spacing(np.abs(ref32)).astype(np.float64), 1e-45)
+    xs = rng.uniform(-7, 7, 4000).astype(np.float32)
+    s = np.array([O.raw.orc_det_sin(float(x)) for x in xs])
+    c = np.array([O.raw.orc_det_cos(float(x)) for x in xs])
+    assert np.abs(s - np.sin(xs.astype(np.float64))).max() < 1.5e-7 and np.abs(c - np.cos(xs.astype(np.float64))).max() < 1.5e-7
+    xs = rng.uniform(-1, 1, 4000).astype(np.float32)
+    a = np.array([O.raw.orc_det_asin(float(x)) for x in xs])
+    assert ulps(a, np.arcsin(xs.astype(np.float64))).max() < 4
+    ys, xs2 = rng.uniform(-3, 3, 4000).astype(np.float32), rng.uniform(-3, 3, 4000).astype(np.float32)
+    t = np.array([O.raw.orc_det_atan2(float(y), float(x)) for y, x in zip(ys, xs2)])
+    assert np.abs(t - np.arctan2(ys.astype(np.float64), xs2.astype(np.float64))).max() < 6e-7
+    xs = np.exp(rng.uniform(-16, 3, 4000)).astype(np.float32)
+    lg = np.array([O.raw.orc_det_log(float(x)) for x in xs])
+    assert ulps(lg, np.log(xs.astype(np.float64))).max() < 2
+    p = np.array([O.raw.orc_det_pow(float(x), 1 / 2.2) for x in xs])
+    assert np.abs(p / np.power(xs.astype(np.float64), np.float32(1 / 2.2)) - 1).max() < 2e-6
+    assert O.raw.orc_det_asin(1.0000001) == O.raw.orc_det_asin(1.0) and O.raw.orc_det_atan2(0.0, 0.0) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# oracle path loop: golden images, libm-vs-fixed-sequence agreement, accumulation semantics
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [3, 4, 5])
+def test_oracle_render_matches_golden(scene_small, hdr_pair, mode):
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    e, c = rt.camera(20.0, 15.0, 3.5)
+    img, st = O.render(tris, nodes, hdr, cache, 48, 40, mode, e, c, 0, 4)
+    gold = GOLD[f"small_mode{mode}_img"]
+    same = (bits(img) == bits(gold)) | (np.isnan(img) & np.isnan(gold))
+    assert same.all()
+    assert [st[k] for k in ("paths", "rays", "internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates")] == GOLD[f"small_mode{mode}_stats"].tolist()
+    assert np.isfinite(img).all() and img.mean() > 0.01
+    lib, _ = O.render(tris, nodes, hdr, cache, 48, 40, mode, e, c, 0, 4, use_libm=True)
+    a = rt.tonemap_rgb8(img).astype(np.float64) / 255
+    b = rt.tonemap_rgb8(lib).astype(np.float64) / 255
+    assert np.sqrt(np.mean((a - b) ** 2)) < 0.02     # the fixed sequences are a faithful stand-in for libm
+
+
+def test_oracle_running_mean_equals_explicit_blend(scene_small, hdr_pair):
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    e, c = rt.camera(5.0, 10.0, 3.0)
+    frames = [O.render(tris, nodes, hdr, cache, 24, 20, 5, e, c, f, 1, accumulate=1)[0] for f in range(5)]  # sum mode from 0 = the raw sample
+    last = np.zeros_like(frames[0])
+    for f, col in enumerate(frames):
+        a = np.float32(1.0) / np.float32(f + 1)
+        last = last * (np.float32(1.0) - a) + col * a        # mix(lastColor, color, 1/(frameCounter+1)), f5:955
+    once, _ = O.render(tris, nodes, hdr, cache, 24, 20, 5, e, c, 0, 5)
+    assert np.array_equal(bits(once), bits(last))
+    cont, _ = O.render(tris, nodes, hdr, cache, 24, 20, 5, e, c, 0, 2)
+    cont, _ = O.render(tris, nodes, hdr, cache, 24, 20, 5, e, c, 2, 3, accum=cont)
+    assert np.array_equal(bits(cont), bits(once))
+
+
+def test_frame_partition_covers_each_frame_once():
+    for world in (1, 2, 4, 8):
+        seen = []
+        for step in range(3):
+            for rank in range(world):
+                b, n = parallel.frame_range(step, rank, world, 16)
+                seen += list(range(b, b + n))
+        assert sorted(seen) == list(range(parallel.frames_covered(3, world, 16)))
+    with pytest.raises(ValueError):
+        parallel.frame_range(0, 2, 2, 16)

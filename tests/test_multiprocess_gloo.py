@@ -1,0 +1,72 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the spp-split + single reduce (ray_tracing_amd/parallel.py, the code
+bench.py runs over RCCL).  The per-rank renderer here is the CPU oracle in SUM mode (test stand-in for rt_render_device,
+which is bit-identical to it on a GPU: tests/test_gpu_parity.py::test_sum_mode_matches_oracle_and_mean)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import torch
+    import torch.distributed as dist
+
+    import oracle_lib as O
+    import ray_tracing_amd as rt
+    from ray_tracing_amd import parallel, scenes
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    tris, nodes = scenes.small_scene()
+    hdr, cache = scenes.hdr_and_cache()
+    eye, cam = rt.camera(10.0, 12.0, 3.2)
+    W, H, spp, steps = 40, 32, 3, 2
+    total = torch.zeros((H, W, 3), dtype=torch.float32)
+    for step in range(steps):
+        fb, fc = parallel.frame_range(step, rank, world, spp)
+        acc, _ = O.render(tris, nodes, hdr, cache, W, H, 5, eye, cam, fb, fc, accumulate=1)
+        t = torch.from_numpy(acc)
+        parallel.reduce_sum(t, dist, dst=0)          # ONE collective per step
+        if rank == 0:
+            total += t
+    if rank == 0:
+        mean = parallel.normalize(total, parallel.frames_covered(steps, world, spp)).numpy()
+        np.save(os.path.join(outdir, "mean.npy"), mean)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_spp_split_two_ranks_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import ray_tracing_amd as rt
+    from ray_tracing_amd import scenes
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "mean.npy")
+    tris, nodes = scenes.small_scene()
+    hdr, cache = scenes.hdr_and_cache()
+    eye, cam = rt.camera(10.0, 12.0, 3.2)
+    n = 2 * world * 3
+    ref_sum, _ = O.render(tris, nodes, hdr, cache, 40, 32, 5, eye, cam, 0, n, accumulate=1)
+    ref_mean, _ = O.render(tris, nodes, hdr, cache, 40, 32, 5, eye, cam, 0, n)
+    # same samples, different fp32 summation order: equal to rounding, not to the bit
+    assert np.allclose(got, ref_sum / n, rtol=1e-5, atol=1e-6)
+    assert np.allclose(got, ref_mean, rtol=1e-4, atol=1e-5)      # and to the reference's running mean (f5:955)
