@@ -97,6 +97,13 @@ int rt_write_png(const char* path, int width, int height, const unsigned char* i
 
 void rt_free(void* p);
 
+/* Chapter 1 (config 1, host only): the CPU Cornell-box tracer of path_tracing_1chap/path_tracing.cpp — scene literal
+ * c1:355-400, shoot c1:214-225, pathTracing c1:277-324, pixel loop c1:409-475 — race-free (one mt19937 per image row,
+ * seeded from `seed`; the reference shares one generator between 50 threads).  `image` = W*H*3 doubles, row 0 = top
+ * (c1:404, 417); rt_chap1_to_rgb8 = imshow(), c1:326-347 (gamma 1/1.9, truncation). */
+int rt_chap1_render(int width, int height, int samples, unsigned seed, double* image);
+int rt_chap1_to_rgb8(const double* image, int width, int height, unsigned char* out_rgb8);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Device layer (HIP, gfx950): the per-pixel path loop.
  * ------------------------------------------------------------------------------------------------------------------ */

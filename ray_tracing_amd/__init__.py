@@ -288,3 +288,18 @@ def kernel_time_ms(reset: bool = True):
     ms, n = C.c_float(), C.c_int()
     _check(_lib.rt_kernel_time_ms(C.byref(ms), C.byref(n), 1 if reset else 0))
     return ms.value, n.value
+
+
+def chap1_render(width: int = 256, height: int = 256, samples: int = 64, seed: int = 1) -> np.ndarray:
+    """Chapter 1 CPU Cornell box (path_tracing_1chap/path_tracing.cpp main(), c1:351-489): (H, W, 3) float64, row 0 = top."""
+    img = np.zeros((height, width, 3), np.float64)
+    _check(_lib.rt_chap1_render(width, height, samples, C.c_uint(seed), img.ctypes.data_as(C.c_void_p)))
+    return img
+
+
+def chap1_to_rgb8(image: np.ndarray) -> np.ndarray:
+    """imshow(), c1:326-347."""
+    image = np.ascontiguousarray(image, np.float64)
+    out = np.empty(image.shape, np.uint8)
+    _check(_lib.rt_chap1_to_rgb8(image.ctypes.data_as(C.c_void_p), image.shape[1], image.shape[0], out.ctypes.data_as(C.c_void_p)))
+    return out

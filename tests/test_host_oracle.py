@@ -333,3 +333,31 @@ def test_frame_partition_covers_each_frame_once():
         assert sorted(seen) == list(range(parallel.frames_covered(3, world, 16)))
     with pytest.raises(ValueError):
         parallel.frame_range(0, 2, 2, 16)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 1: chapter-1 CPU Cornell box (host only).  The reference seeds mt19937 from random_device (c1:227-229), so
+# parity with its render (sample_4096.png -> tests/golden/chap1_sample4096_linear_64x64.npy) is statistical.
+# Full config (256x256 @ 4096 spp: relative mean <= 2 %, RMSE <= 0.03) takes minutes; the suite runs a reduced one.
+# ---------------------------------------------------------------------------------------------------------------
+def test_chap1_cornell_statistical_parity_with_reference_render():
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "chap1_sample4096_linear_64x64.npy")).astype(np.float64)
+    img = rt.chap1_render(128, 128, 192, seed=3)
+    assert img.max() == 192.0                       # emissive pixels are not scaled by BRIGHTNESS (c1:436-439): sum = SAMPLE
+    q = rt.chap1_to_rgb8(img).astype(np.float64)
+    small = ((q / 255.0) ** 1.9).reshape(64, 2, 64, 2, 3).mean(axis=(1, 3))
+    assert abs(small.mean() - ref.mean()) <= 0.03 * ref.mean()
+    assert np.all(np.abs(small.mean((0, 1)) - ref.mean((0, 1))) <= 0.05 * ref.mean((0, 1)))
+    g = lambda x: x ** (1 / 1.9)
+    assert np.sqrt(np.mean((g(small) - g(ref)) ** 2)) <= 0.07
+
+
+def test_chap1_is_deterministic_per_seed_and_thread_count():
+    a = rt.chap1_render(48, 40, 8, seed=5)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    b = rt.chap1_render(48, 40, 8, seed=5)
+    c = rt.chap1_render(48, 40, 8, seed=6)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    rgb = rt.chap1_to_rgb8(a)
+    exp = np.clip(np.power(a, np.float32(1.0) / np.float32(1.9)) * 255, 0, 255).astype(np.uint8)
+    assert np.abs(rgb.astype(int) - exp.astype(int)).max() <= 1
