@@ -74,7 +74,8 @@ struct RenderParams {
     int* spill;            // global stack spill, [depth - kLdsDepth][thread]
     long long spill_stride;
     unsigned long long* stats;  // 6 counters (STATS builds)
-    int refill;            // lanes waiting for a handler that end the shared traversal loop
+    int refill;            // lanes waiting for a handler that trigger a handler pass
+    int leaf_lanes;        // lanes holding a leaf that trigger a cooperative leaf pass
     int32_t* hit_tri;      // primary-hit query outputs
     float* hit_dist;
 };
@@ -314,7 +315,7 @@ __device__ __forceinline__ void flush_stats(const RenderParams& P, const Stats& 
 enum LaneOp { OP_INT = 0, OP_LEAF = 1, OP_A = 2, OP_C = 3, OP_D = 4, OP_DONE = 5 };
 enum RayKind { K_PRIMARY = 0, K_SHADOW = 1, K_BOUNCE = 2, K_NONE = 3 };
 
-constexpr int kHandlerLanes = 12;  // run a handler once this many lanes wait for it (or nothing is traversing)
+constexpr int kHandlerLanes = 20;  // run a handler once this many lanes wait for it (or nothing is traversing)
 
 // hitAABB (f5:225-238) with hardware min/max.  Equal to the ternary form whenever no operand is NaN (the results are
 // only compared, so the sign of a zero does not matter); rays that can produce NaN (a zero/NaN direction component or a
@@ -331,16 +332,37 @@ __device__ __forceinline__ bool finite3(vec3 v) {
     return (fabs_(v.x) < inf) && (fabs_(v.y) < inf) && (fabs_(v.z) < inf);
 }
 
+constexpr int kWave = 64;         // render_kernel: one wave64 per workgroup, an 8x8 pixel tile
+constexpr int kLeafLanes = 10;    // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
+
+template <bool SPILL>
+__device__ __forceinline__ void wstack_push(int* lds, int* spill, long long stride, int sp, int v) {
+    if (!SPILL || sp < kLdsDepth)
+        lds[sp * kWave] = v;
+    else
+        spill[(long long)(sp - kLdsDepth) * stride] = v;
+}
+template <bool SPILL>
+__device__ __forceinline__ int wstack_pop(const int* lds, const int* spill, long long stride, int sp) {
+    if (!SPILL || sp < kLdsDepth) return lds[sp * kWave];
+    return spill[(long long)(sp - kLdsDepth) * stride];
+}
+
 template <int MODE, bool STATS, bool SPILL>
-__global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
-    __shared__ int s_stack[kLdsDepth * kBlock];
+__global__ void __launch_bounds__(kWave) render_kernel(const RenderParams P) {
+    __shared__ int s_stack[kLdsDepth * kWave];        // per-lane traversal stacks, [depth][lane]
+    __shared__ float4 s_ray[2 * kWave];                // per-lane ray in flight: (S.xyz, d.x) (d.yz, -, -)
+    __shared__ int s_item[kWave];                      // cooperative leaf pass: item -> (triangle << 6 | owner lane)
+    __shared__ unsigned long long s_key[kWave];        // per owner: min over its items of (t bits << 32 | triangle)
+    __shared__ float s_t[kWave];                       // STATS builds: per item hit distance (INF = miss)
     const DevScene& sc = P.sc;
-    int px, py;
-    const bool active = lane_pixel(P, &px, &py);
-    LaneStack stk;
-    stk.lds = &s_stack[threadIdx.x];
-    stk.stride = P.spill_stride;
-    stk.spill = SPILL ? (P.spill + ((long long)blockIdx.x * kBlock + threadIdx.x)) : nullptr;
+    const int lane = threadIdx.x;
+    const int tilesx = (P.width + 7) >> 3;
+    const int px = (blockIdx.x % tilesx) * 8 + (lane & 7), py = (blockIdx.x / tilesx) * 8 + (lane >> 3);
+    const bool active = px < P.width && py < P.height;
+    int* const stk_lds = &s_stack[lane];
+    int* const stk_spill = SPILL ? (P.spill + ((long long)blockIdx.x * kWave + lane)) : nullptr;
+    const long long stk_stride = P.spill_stride;
     Stats st = {0, 0, 0, 0, 0};
     unsigned long long paths = 0;
     unsigned dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // STATS builds: passes / active-lane sums per op
@@ -528,6 +550,8 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
                 best = INF_, best_tri = -1, sp = 0, cur = sc.root_entry;
                 invdir = v3(1.0f) / d;
                 slow = !(finite3(invdir) && finite3(S));
+                s_ray[2 * lane] = make_float4(S.x, S.y, S.z, d.x);  // for the cooperative leaf pass
+                s_ray[2 * lane + 1] = make_float4(d.y, d.z, 0.0f, 0.0f);
                 if (!sc.has_root) {
                     op = (kind == K_PRIMARY) ? OP_A : ((kind == K_SHADOW) ? OP_C : OP_D);
                 } else if (cur >= 0) {
@@ -555,10 +579,10 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
                 bool popped = false;
                 if (d1 > 0.0f && d2 > 0.0f) {
                     if (d1 < d2) {  // left first
-                        stack_push<SPILL>(stk, sp++, re);
+                        wstack_push<SPILL>(stk_lds, stk_spill, stk_stride, sp++, re);
                         cur = le;
                     } else {        // right first (ties included)
-                        stack_push<SPILL>(stk, sp++, le);
+                        wstack_push<SPILL>(stk_lds, stk_spill, stk_stride, sp++, le);
                         cur = re;
                     }
                 } else if (d1 > 0.0f) {
@@ -569,7 +593,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
                     op = (kind == K_PRIMARY) ? OP_A : ((kind == K_SHADOW) ? OP_C : OP_D);
                     popped = true;
                 } else {
-                    cur = stack_pop<SPILL>(stk, --sp);
+                    cur = wstack_pop<SPILL>(stk_lds, stk_spill, stk_stride, --sp);
                 }
                 if (!popped && cur < 0) {
                     op = OP_LEAF, ti = cur & 0x00ffffff, leaf_best = INF_;
@@ -577,31 +601,67 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
                 }
             }
         } else {
-            // ---- one triangle of the leaf in `cur` (hitArray, f5:243-256) ----------------------------------------
-            if (op == OP_LEAF) {
-                const int end = (cur & 0x00ffffff) + ((cur >> 24) & 0x7f) + 1;
-                const float4 a = sc.ttri[ti * 3 + 0], b = sc.ttri[ti * 3 + 1], c = sc.ttri[ti * 3 + 2];
+            // ---- cooperative leaf pass (hitArray, f5:243-256) ------------------------------------------------------
+            // Every lane holding a leaf owns `rem` pending triangles.  The (owner, triangle) pairs of the whole wave are
+            // laid out back to back (wave prefix sum), the first 64 become this pass's items and item k is tested by
+            // lane k against its OWNER's ray (read from the LDS ray table).  Per owner the items reduce through one LDS
+            // atomic min on (t bits << 32 | triangle index): the smallest t, the lowest index on a tie — what the
+            // sequential scan with strict < keeps — and the owner then applies `t < best` (strict: an earlier leaf keeps
+            // a tie, f5:278).  Triangles are consumed in index order, leaves in stack order: per ray nothing changes.
+            const bool leaf = (op == OP_LEAF);
+            const int end = (cur & 0x00ffffff) + ((cur >> 24) & 0x7f) + 1;
+            const int rem = leaf ? (end - ti) : 0;
+            int incl = rem;  // inclusive prefix sum over the wave
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            const int start = incl - rem;
+            int serve = 64 - start;
+            serve = serve < 0 ? 0 : (serve > rem ? rem : serve);
+            const int total = __shfl(incl, 63, 64);
+            const int n_items = total < 64 ? total : 64;
+            if (leaf) s_key[lane] = ~0ull;
+            for (int j = 0; __any(j < serve); ++j)
+                if (j < serve) s_item[start + j] = ((ti + j) << 6) | lane;
+            __syncthreads();  // one wave per workgroup: a fence only
+            if (lane < n_items) {
+                const int it = s_item[lane];
+                const int owner = it & 63, tri = it >> 6;
+                const float4 r0 = s_ray[2 * owner], r1 = s_ray[2 * owner + 1];
+                const float4 a = sc.ttri[tri * 3 + 0], b = sc.ttri[tri * 3 + 1], c = sc.ttri[tri * 3 + 2];
                 float t;
+                const bool hit = hitTriangleT(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), v3(c.y, c.z, c.w),
+                                              v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y), &t);
+                if (hit) atomicMin(&s_key[owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)tri);
+                if (STATS) s_t[lane] = hit ? t : INF_;
+            }
+            __syncthreads();
+            if (leaf && serve > 0) {
                 bool done = false;
-                if (STATS) st.tris++;
-                if (hitTriangleT(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), S, d, &t)) {
-                    if (STATS && t < leaf_best) {
-                        st.updates++;
-                        leaf_best = t;
+                if (STATS) {
+                    st.tris += serve;
+                    for (int j = 0; j < serve; ++j) {  // H = improvements inside hitArray, counted in scan order
+                        const float tj = s_t[start + j];
+                        if (tj < leaf_best) st.updates++, leaf_best = tj;
                     }
-                    if (t < best) {  // strict <: the first visited candidate keeps a tie (f5:250, 278)
+                }
+                const unsigned long long key = s_key[lane];
+                if (key != ~0ull) {
+                    const float t = __uint_as_float((unsigned)(key >> 32));
+                    if (t < best) {
                         best = t;
-                        best_tri = ti;
+                        best_tri = (int)(unsigned)key;
                         // an env-visibility ray only needs isHit (f5:869); statistics builds count the full walk
                         if (!STATS && kind == K_SHADOW) done = true;
                     }
                 }
-                ti++;
+                ti += serve;
                 if (!done && ti >= end) {
                     if (sp == 0) {
                         done = true;
                     } else {
-                        cur = stack_pop<SPILL>(stk, --sp);
+                        cur = wstack_pop<SPILL>(stk_lds, stk_spill, stk_stride, --sp);
                         if (cur >= 0) {
                             op = OP_INT;
                         } else {
@@ -612,6 +672,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
                 }
                 if (done) op = (kind == K_PRIMARY) ? OP_A : ((kind == K_SHADOW) ? OP_C : OP_D);
             }
+            if (STATS && lane == 0) dg[10]++, dg[11] += n_items;
         }
 
         // ---- scheduler: ballot the populations, pick the next op ---------------------------------------------------
@@ -621,13 +682,14 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const RenderParams P) {
         int hb = OP_A, hn = nA;
         if (nC > hn) hb = OP_C, hn = nC;
         if (nD > hn) hb = OP_D, hn = nD;
-        const int tb = (nL > nI) ? OP_LEAF : OP_INT, tn = (nL > nI) ? nL : nI;
+        // traversal: internal steps until enough lanes hold a leaf to fill a cooperative leaf pass
+        const int tb = (nL >= P.leaf_lanes || nI == 0) ? OP_LEAF : OP_INT, tn = nI + nL;
         pick = (tn == 0 || hn >= P.refill) ? hb : tb;
-        if (STATS && (threadIdx.x & 63) == 0) dg[2 * pick]++, dg[2 * pick + 1] += (pick >= OP_A) ? hn : tn;
+        if (STATS && lane == 0) dg[2 * pick]++, dg[2 * pick + 1] += (pick >= OP_A) ? hn : ((pick == OP_INT) ? nI : nL);
     }
     if (STATS) {
         flush_stats(P, st, paths);
-        if ((threadIdx.x & 63) == 0)
+        if (lane == 0)
             for (int k = 0; k < 12; ++k) atomicAdd(&P.stats[6 + k], (unsigned long long)dg[k]);
     }
 }
@@ -851,19 +913,22 @@ static int check_desc(const rt_scene* s, const rt_render_desc* d, const char* wh
     return RT_OK;
 }
 
-static int fill_params(rt_scene* s, const rt_render_desc* d, RenderParams* P, int* blocks) {
+static int fill_params(rt_scene* s, const rt_render_desc* d, RenderParams* P, int* blocks, bool render) {
     memset(P, 0, sizeof(*P));
     P->sc = s->dev;
     P->width = d->width, P->height = d->height;
     P->accumulate = d->accumulate;
     memcpy(P->eye, d->eye, sizeof(P->eye));
     memcpy(P->cam, d->camera_rotate, sizeof(P->cam));
-    const int tilesx = (d->width + 15) / 16, tilesy = (d->height + 15) / 16;
-    *blocks = tilesx * tilesy;
+    // render_kernel: one wave64 per 8x8 tile; primary_kernel: 256 threads per 16x16 tile
+    const int tile = render ? 8 : 16, block_threads = render ? kWave : kBlock;
+    *blocks = ((d->width + tile - 1) / tile) * ((d->height + tile - 1) / tile);
+    P->leaf_lanes = kLeafLanes;
+    if (const char* e = getenv("RT_AMD_LEAF")) P->leaf_lanes = atoi(e) > 0 ? atoi(e) : kLeafLanes;  // tuning knob
     P->refill = kHandlerLanes;
     if (const char* e = getenv("RT_AMD_REFILL")) P->refill = atoi(e) > 0 ? atoi(e) : kHandlerLanes;  // tuning knob
     if (s->max_stack > kLdsDepth) {  // deep tree: per-thread global spill beyond the LDS part of the stack
-        const size_t threads = (size_t)*blocks * kBlock;
+        const size_t threads = (size_t)*blocks * block_threads;
         const size_t bytes = threads * (size_t)(s->max_stack - kLdsDepth) * sizeof(int);
         if (bytes > s->spill_bytes) {
             (void)hipFree(s->d_spill);
@@ -894,7 +959,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
     HIPCHK(hipSetDevice(s->device));
     RenderParams P;
     int blocks;
-    rc = fill_params(s, d, &P, &blocks);
+    rc = fill_params(s, d, &P, &blocks, true);
     if (rc != RT_OK) return rc;
     P.max_bounce = d->max_bounce > 0 ? d->max_bounce : (d->mode == RT_MODE_CHAP5 ? 4 : 6);
     P.frame_begin = frame_begin, P.frame_count = frame_count;
@@ -908,9 +973,9 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
 #define LAUNCH(MODE_)                                                                                   \
     do {                                                                                                \
         if (spill)                                                                                      \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, true>), dim3(blocks), dim3(kBlock), 0, stream, P);  \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, true>), dim3(blocks), dim3(kWave), 0, stream, P);  \
         else                                                                                            \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, false>), dim3(blocks), dim3(kBlock), 0, stream, P); \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, false>), dim3(blocks), dim3(kWave), 0, stream, P); \
     } while (0)
     if (d->mode == RT_MODE_CHAP5)
         LAUNCH(RT_MODE_CHAP5);
@@ -983,8 +1048,8 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_render_stats: %s", hipGetErrorString(e));
     if (getenv("RT_AMD_DIAG")) {
-        static const char* nm[6] = {"OP_INT", "OP_LEAF", "OP_A(primary)", "OP_C(shadow)", "OP_D(bounce)", "-"};
-        for (int k = 0; k < 5; ++k)
+        static const char* nm[6] = {"OP_INT", "OP_LEAF (lanes)", "OP_A(primary)", "OP_C(shadow)", "OP_D(bounce)", "leaf items"};
+        for (int k = 0; k < 6; ++k)
             fprintf(stderr, "[rt diag] %-18s wave passes %llu, mean active lanes %.1f\n", nm[k], h[6 + 2 * k], h[6 + 2 * k] ? (double)h[7 + 2 * k] / (double)h[6 + 2 * k] : 0.0);
     }
     out->paths = h[0], out->rays = h[1], out->internal_nodes = h[2], out->leaf_nodes = h[3];
@@ -999,7 +1064,7 @@ int rt_primary_hits_device(rt_scene* s, const rt_render_desc* d, int32_t* tri_de
     HIPCHK(hipSetDevice(s->device));
     RenderParams P;
     int blocks;
-    rc = fill_params(s, d, &P, &blocks);
+    rc = fill_params(s, d, &P, &blocks, false);
     if (rc != RT_OK) return rc;
     P.hit_tri = tri_dev, P.hit_dist = dist_dev;
     TimedLaunch tl;
