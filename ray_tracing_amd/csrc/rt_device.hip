@@ -312,10 +312,10 @@ __device__ __forceinline__ void flush_stats(const RenderParams& P, const Stats& 
 // handler that serves them).  Cheap traversal steps keep running while lanes accumulate at the expensive handlers, so
 // each handler pass is executed by many lanes, whatever frame, bounce or ray kind each lane is in.  Per lane the sequence
 // of nodes, leaves, triangles, arithmetic and RNG calls is exactly the reference's.
-enum LaneOp { OP_INT = 0, OP_LEAF = 1, OP_A = 2, OP_C = 3, OP_D = 4, OP_DONE = 5 };
+enum LaneOp { OP_INT = 0, OP_LEAF = 1, OP_H = 2, OP_DONE = 3 };
 enum RayKind { K_PRIMARY = 0, K_SHADOW = 1, K_BOUNCE = 2, K_NONE = 3 };
 
-constexpr int kHandlerLanes = 20;  // run a handler once this many lanes wait for it (or nothing is traversing)
+constexpr int kHandlerLanes = 40;  // run a handler once this many lanes wait for it (or nothing is traversing)
 
 // hitAABB (f5:225-238) with hardware min/max.  Equal to the ternary form whenever no operand is NaN (the results are
 // only compared, so the sign of a zero does not matter); rays that can produce NaN (a zero/NaN direction component or a
@@ -333,7 +333,7 @@ __device__ __forceinline__ bool finite3(vec3 v) {
 }
 
 constexpr int kWave = 64;         // render_kernel: one wave64 per workgroup, an 8x8 pixel tile
-constexpr int kLeafLanes = 10;    // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
+constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
 
 template <bool SPILL>
 __device__ __forceinline__ void wstack_push(int* lds, int* spill, long long stride, int sp, int v) {
@@ -392,105 +392,99 @@ __global__ void __launch_bounds__(kWave) render_kernel(const RenderParams P) {
     vec3 Lo = v3(0), history = v3(1);
 
     bool need_new = active;         // start the first sample in the prologue pass
-    int pick = OP_A;                // the prologue runs the handler tail once with no handler body
+    int pick = OP_H;                // the prologue runs the shade pass once with no lane in OP_H: only its tail
     for (;;) {
-        if (pick >= OP_A) {
-            bool to_B = false, fin = false, emit = false;
-            // ---- OP_D: the BRDF ray came back --------------------------------------------------------------------
-            if (pick == OP_D && op == OP_D) {
+        if (pick >= OP_H) {
+            // ---- the shade pass: every lane whose ray came back (primary / env-visibility / BRDF ray, told apart by
+            // `kind`), step by step; a step runs once for all lanes that need it ------------------------------------
+            bool to_B = false, to_C = false, fin = false, emit = false;
+            const bool h = (op == OP_H);
+            const bool isA = h && kind == K_PRIMARY, isD = h && kind == K_BOUNCE;
+            const bool isC = h && (kind == K_SHADOW || kind == K_NONE);
+            const bool miss = best_tri < 0;
+            const vec3 L = d;  // direction of the ray that came back
+            // step 1: BRDF value (and sampling pdf) for L at the current surface point: the BRDF ray always (f5:899-900,
+            // f4:520, f3:396), the env-visibility ray when it was not occluded (f5:875-876)
+            vec3 f_r = v3(0);
+            float pdf_brdf = 0.0f;
+            const bool need_eval = isD || (h && kind == K_SHADOW && miss);
+            if (need_eval) {
                 const Mat mat = load_material(sc, surf_tri);
-                const vec3 L = d;
                 if (MODE == RT_MODE_CHAP5) {
-                    const float NdotL = dot(N, L);
-                    float pdf_brdf;
-                    const vec3 f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
-                    if (pdf_brdf <= 0.0f) {
-                        fin = true;
-                    } else if (best_tri < 0) {
-                        const vec3 color = envColor<MODE>(sc, L);
-                        const float pdf_light = envPdf(sc, L);
-                        const float mis_weight = misMixWeight(pdf_brdf, pdf_light);
-                        Lo += mis_weight * history * color * NdotL * f_r / pdf_brdf;
-                        fin = true;
-                    } else {
-                        const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
-                        const float* T = sc.tris + (size_t)best_tri * 36 + 18;
-                        const vec3 Le = v3(T[0], T[1], T[2]);
-                        Lo += history * Le * NdotL * f_r / pdf_brdf;
-                        history *= NdotL * f_r / pdf_brdf;
-                        hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
-                        bounce++;
-                        if (bounce < P.max_bounce) to_B = true; else fin = true;
-                    }
+                    f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
+                } else if (MODE == RT_MODE_CHAP4) {
+                    vec3 tangent, bitangent;
+                    getTagent(N, tangent, bitangent);
+                    f_r = disney_eval<true, false>(V, N, L, tangent, bitangent, mat, nullptr);
                 } else {
-                    const float pdf = 1.0f / (2.0f * PI_);
-                    const float cosine_i = fmax_(0.0f, dot(N, L));
-                    vec3 f_r;
-                    if (MODE == RT_MODE_CHAP4) {
-                        vec3 tangent, bitangent;
-                        getTagent(N, tangent, bitangent);
-                        f_r = disney_eval<true, false>(V, N, L, tangent, bitangent, mat, nullptr);
-                    } else {
-                        f_r = mat.baseColor / PI_;
-                    }
-                    if (best_tri < 0) {
-                        const vec3 skyColor = envColor<MODE>(sc, L);
-                        Lo += history * skyColor * f_r * cosine_i / pdf;
-                        fin = true;
-                    } else {
-                        const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
-                        const float* T = sc.tris + (size_t)best_tri * 36 + 18;
-                        const vec3 Le = v3(T[0], T[1], T[2]);
-                        if (MODE == RT_MODE_CHAP4)
-                            Lo += history * Le * cosine_i / pdf;        // f4:535: no f_r
-                        else
-                            Lo += history * Le * f_r * cosine_i / pdf;  // f3:407
-                        history *= f_r * cosine_i / pdf;
-                        hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
-                        bounce++;
-                        if (bounce < P.max_bounce) to_B = true; else fin = true;
-                    }
+                    f_r = mat.baseColor / PI_;
                 }
             }
-            // ---- OP_A: the primary ray came back -----------------------------------------------------------------
-            if (pick == OP_A && op == OP_A) {
-                if (best_tri < 0) {
-                    Lo = envColor<MODE>(sc, d);
-                    first_tri = -1;
+            // step 2: environment radiance (and its pdf) along L for every ray that escaped (f5:945, 873-874, 906-907)
+            const bool d_alive = isD && (MODE != RT_MODE_CHAP5 || !(pdf_brdf <= 0.0f));  // f5:901
+            const bool need_env = (isA && miss) || (h && kind == K_SHADOW && miss) || (d_alive && miss);
+            vec3 color = v3(0);
+            float pdf_light = 0.0f;
+            if (need_env) {
+                if (sc.hdr) {
+                    float eu, ew;
+                    toSphericalCoord(normalize(L), &eu, &ew);
+                    const int texel = texel_index(ew, sc.hdrH) * sc.hdrW + texel_index(eu, sc.hdrW);
+                    const float4 c = sc.hdr[texel];
+                    color = v3(c.x, c.y, c.z);
+                    if (MODE != RT_MODE_CHAP5) color = min3(color, v3(10));  // f4:162
+                    if (MODE == RT_MODE_CHAP5 && !isA) pdf_light = hdrPdfConvert(sc.cache[texel].z, ew, sc.hdrW);  // hdrPdf, f5:648-660
+                }
+            }
+            // step 3: what each kind of ray adds
+            if (isA && miss) {
+                Lo = color, first_tri = -1, fin = true;
+            }
+            if (MODE == RT_MODE_CHAP5 && h && kind == K_SHADOW && miss) {
+                const float mis_weight = misMixWeight(pdf_light, pdf_brdf);
+                Lo += mis_weight * history * color * f_r * dot(N, L) / pdf_light;  // f5:879-880
+            }
+            const float cosine_i = fmax_(0.0f, dot(N, L));  // chapters 3/4
+            const float pdf_uniform = 1.0f / (2.0f * PI_);
+            if (isD) {
+                if (MODE == RT_MODE_CHAP5) {
+                    if (!d_alive) {
+                        fin = true;
+                    } else if (miss) {
+                        const float NdotL = dot(N, L);
+                        const float mis_weight = misMixWeight(pdf_brdf, pdf_light);
+                        Lo += mis_weight * history * color * NdotL * f_r / pdf_brdf;  // f5:910-911
+                        fin = true;
+                    }
+                } else if (miss) {
+                    Lo += history * color * f_r * cosine_i / pdf_uniform;  // f4:530, f3:401
                     fin = true;
+                }
+            }
+            // step 4: the ray hit a surface: finish the hit record (smooth normal), move the path there
+            if ((isA || d_alive) && !miss) {
+                const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
+                if (isD) {
+                    const float* T = sc.tris + (size_t)best_tri * 36 + 18;
+                    const vec3 Le = v3(T[0], T[1], T[2]);
+                    if (MODE == RT_MODE_CHAP5) {
+                        const float NdotL = dot(N, L);
+                        Lo += history * Le * NdotL * f_r / pdf_brdf;  // f5:915
+                        history *= NdotL * f_r / pdf_brdf;            // f5:920
+                    } else {
+                        if (MODE == RT_MODE_CHAP4)
+                            Lo += history * Le * cosine_i / pdf_uniform;        // f4:535: no f_r
+                        else
+                            Lo += history * Le * f_r * cosine_i / pdf_uniform;  // f3:407
+                        history *= f_r * cosine_i / pdf_uniform;
+                    }
+                    bounce++;
                 } else {
-                    const Hit h = finish_hit<MODE>(sc, S, d, best_tri, best);
-                    hitP = h.hitPoint, N = h.normal, V = -h.viewDir, surf_tri = best_tri;
                     first_tri = best_tri;
                     Lo = v3(0), history = v3(1), bounce = 0;
-                    if (bounce < P.max_bounce) to_B = true; else fin = true;
                 }
-            }
-            // ---- OP_C (chap5): env-visibility result (f5:869-881), then BRDF sampling (f5:883-895) ---------------
-            if (MODE == RT_MODE_CHAP5 && pick == OP_C && op == OP_C) {
-                const Mat mat = load_material(sc, surf_tri);
-                if (kind == K_SHADOW && best_tri < 0) {
-                    const vec3 L = d;
-                    const vec3 color = envColor<MODE>(sc, L);
-                    const float pdf_light = envPdf(sc, L);
-                    float pdf_brdf;
-                    const vec3 f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
-                    const float mis_weight = misMixWeight(pdf_light, pdf_brdf);
-                    Lo += mis_weight * history * color * f_r * dot(N, L) / pdf_light;
-                }
-                const unsigned frame = (unsigned)(P.frame_begin + f);
-                const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
-                const float su = sobol_dim(d_sobolV, bounce * 2, gray);
-                const float sv = sobol_dim(d_sobolV, bounce * 2 + 1, gray);
-                const float xi_1 = cp_rotate(su, cpu);
-                const float xi_2 = cp_rotate(sv, cpv);
-                const float xi_3 = rand01(seed);
-                const vec3 L = SampleBRDF(xi_1, xi_2, xi_3, V, N, mat);
-                if (dot(N, L) <= 0.0f) {
-                    fin = true;
-                } else {
-                    S = hitP, d = L, kind = K_BOUNCE, emit = true;
-                }
+                hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
+                if (bounce < P.max_bounce) to_B = true; else fin = true;
             }
             // ---- start of a bounce (f5:856-866 env sample; chapters 3/4: the hemisphere sample) ------------------
             if (to_B) {
@@ -501,25 +495,42 @@ __global__ void __launch_bounds__(kWave) render_kernel(const RenderParams P) {
                     if (dot(N, Lh) > 0.0f) {
                         S = hitP, d = Lh, kind = K_SHADOW, emit = true;
                     } else {
-                        kind = K_NONE, op = OP_C;  // no visibility ray: straight to BRDF sampling
+                        kind = K_NONE, to_C = true;  // no visibility ray: straight to BRDF sampling
                     }
                 } else {
-                    const vec3 L = toNormalHemisphere(SampleHemisphereRand(seed), N);
-                    S = hitP, d = L, kind = K_BOUNCE, emit = true;
+                    const vec3 Lu = toNormalHemisphere(SampleHemisphereRand(seed), N);
+                    S = hitP, d = Lu, kind = K_BOUNCE, emit = true;
+                }
+            }
+            // ---- BRDF importance sampling (f5:883-895): after the env-visibility ray, or at once when it was skipped ---
+            if (MODE == RT_MODE_CHAP5 && (isC || to_C)) {
+                const Mat mat = load_material(sc, surf_tri);
+                const unsigned frame = (unsigned)(P.frame_begin + f);
+                const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
+                const float su = sobol_dim(d_sobolV, bounce * 2, gray);
+                const float sv = sobol_dim(d_sobolV, bounce * 2 + 1, gray);
+                const float xi_1 = cp_rotate(su, cpu);
+                const float xi_2 = cp_rotate(sv, cpv);
+                const float xi_3 = rand01(seed);
+                const vec3 Ls = SampleBRDF(xi_1, xi_2, xi_3, V, N, mat);
+                if (dot(N, Ls) <= 0.0f) {
+                    fin = true;
+                } else {
+                    S = hitP, d = Ls, kind = K_BOUNCE, emit = true;
                 }
             }
             // ---- end of a sample: frame blend (f5:954-955) -------------------------------------------------------
             if (fin) {
-                vec3 color = Lo;
+                vec3 sample = Lo;
                 if (first_tri >= 0) {
                     const float* T = sc.tris + (size_t)first_tri * 36 + 18;
-                    color = v3(T[0], T[1], T[2]) + Lo;  // Le + Li, f5:950
+                    sample = v3(T[0], T[1], T[2]) + Lo;  // Le + Li, f5:950
                 }
                 const unsigned frame = (unsigned)(P.frame_begin + f);
                 if (P.accumulate == RT_ACCUM_SUM)
-                    acc = acc + color;
+                    acc = acc + sample;
                 else
-                    acc = mix3(acc, color, 1.0f / (float)(int)(frame + 1u));
+                    acc = mix3(acc, sample, 1.0f / (float)(int)(frame + 1u));
                 if (STATS) paths++;
                 f++;
                 need_new = true;
@@ -553,7 +564,7 @@ __global__ void __launch_bounds__(kWave) render_kernel(const RenderParams P) {
                 s_ray[2 * lane] = make_float4(S.x, S.y, S.z, d.x);  // for the cooperative leaf pass
                 s_ray[2 * lane + 1] = make_float4(d.y, d.z, 0.0f, 0.0f);
                 if (!sc.has_root) {
-                    op = (kind == K_PRIMARY) ? OP_A : ((kind == K_SHADOW) ? OP_C : OP_D);
+                    op = OP_H;
                 } else if (cur >= 0) {
                     op = OP_INT;
                 } else {
@@ -590,7 +601,7 @@ __global__ void __launch_bounds__(kWave) render_kernel(const RenderParams P) {
                 } else if (d2 > 0.0f) {
                     cur = re;
                 } else if (sp == 0) {
-                    op = (kind == K_PRIMARY) ? OP_A : ((kind == K_SHADOW) ? OP_C : OP_D);
+                    op = OP_H;
                     popped = true;
                 } else {
                     cur = wstack_pop<SPILL>(stk_lds, stk_spill, stk_stride, --sp);
@@ -670,22 +681,19 @@ __global__ void __launch_bounds__(kWave) render_kernel(const RenderParams P) {
                         }
                     }
                 }
-                if (done) op = (kind == K_PRIMARY) ? OP_A : ((kind == K_SHADOW) ? OP_C : OP_D);
+                if (done) op = OP_H;
             }
             if (STATS && lane == 0) dg[10]++, dg[11] += n_items;
         }
 
         // ---- scheduler: ballot the populations, pick the next op ---------------------------------------------------
         const int nI = __popcll(__ballot(op == OP_INT)), nL = __popcll(__ballot(op == OP_LEAF));
-        const int nA = __popcll(__ballot(op == OP_A)), nC = __popcll(__ballot(op == OP_C)), nD = __popcll(__ballot(op == OP_D));
-        if ((nI | nL | nA | nC | nD) == 0) break;
-        int hb = OP_A, hn = nA;
-        if (nC > hn) hb = OP_C, hn = nC;
-        if (nD > hn) hb = OP_D, hn = nD;
+        const int nH = __popcll(__ballot(op == OP_H));
+        if ((nI | nL | nH) == 0) break;
         // traversal: internal steps until enough lanes hold a leaf to fill a cooperative leaf pass
         const int tb = (nL >= P.leaf_lanes || nI == 0) ? OP_LEAF : OP_INT, tn = nI + nL;
-        pick = (tn == 0 || hn >= P.refill) ? hb : tb;
-        if (STATS && lane == 0) dg[2 * pick]++, dg[2 * pick + 1] += (pick >= OP_A) ? hn : ((pick == OP_INT) ? nI : nL);
+        pick = (tn == 0 || nH >= P.refill) ? OP_H : tb;
+        if (STATS && lane == 0) dg[2 * pick]++, dg[2 * pick + 1] += (pick == OP_H) ? nH : ((pick == OP_INT) ? nI : nL);
     }
     if (STATS) {
         flush_stats(P, st, paths);
@@ -1048,7 +1056,7 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_render_stats: %s", hipGetErrorString(e));
     if (getenv("RT_AMD_DIAG")) {
-        static const char* nm[6] = {"OP_INT", "OP_LEAF (lanes)", "OP_A(primary)", "OP_C(shadow)", "OP_D(bounce)", "leaf items"};
+        static const char* nm[6] = {"OP_INT", "OP_LEAF (lanes)", "OP_H(shade)", "-", "-", "leaf items"};
         for (int k = 0; k < 6; ++k)
             fprintf(stderr, "[rt diag] %-18s wave passes %llu, mean active lanes %.1f\n", nm[k], h[6 + 2 * k], h[6 + 2 * k] ? (double)h[7 + 2 * k] / (double)h[6 + 2 * k] : 0.0);
     }
