@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libray_tracing_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "libray_tracing_amd.so")
 ASSETS = os.path.join(os.path.dirname(_HERE), "assets")
 
 if not os.path.exists(LIB_PATH):

@@ -31,7 +31,13 @@ namespace rta {
     } while (0)
 
 constexpr int kBlock = 256;      // 16x16 pixels; each wave64 owns an 8x8 sub-tile
-constexpr int kLdsDepth = 32;    // per-lane stack entries kept in LDS
+#ifndef RT_LDS_DEPTH
+#define RT_LDS_DEPTH 18
+#endif
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 5
+#endif
+constexpr int kLdsDepth = RT_LDS_DEPTH;    // per-lane stack entries kept in LDS
 constexpr int kMaxStack = 256;   // int stack[256], f5:265
 
 // Sobol direction numbers, f5:339 (data table: 8 dimensions x 32 bits)
@@ -93,8 +99,10 @@ __device__ __forceinline__ float hitAABB(vec3 S, vec3 invdir, vec3 AA, vec3 BB) 
 
 // ---- T1: hitTriangle (distance part), f5:168-209.  N0 = precomputed normalize(cross(p2-p1, p3-p1)). -------------
 __device__ __forceinline__ bool hitTriangleT(vec3 p1, vec3 p2, vec3 p3, vec3 N0, vec3 S, vec3 d, float* t_out) {
-    vec3 N = N0;
-    if (dot(N, d) > 0.0f) N = -N;
+    // The reference flips N to face the ray first (f5:183-186).  Every later use is odd in N (|dot(N,d)|, the quotient
+    // of two dot products with N, the signs of a,b,c tested for "all > 0 or all < 0"), and fp32 negation commutes with
+    // round-to-nearest products and sums, so the unflipped normal gives bit-identical t and the same accept/reject.
+    const vec3 N = N0;
     if (fabs_(dot(N, d)) < 0.00001f) return false;
     const float t = (dot(N, p1) - dot(S, N)) / dot(d, N);
     if (t < 0.0005f) return false;
@@ -303,15 +311,14 @@ __device__ __forceinline__ void flush_stats(const RenderParams& P, const Stats& 
 // cut at every hitBVH call.  A lane owns one pixel and walks its frames in order.  At any moment a lane waits for exactly
 // one "op":
 //   OP_INT   one internal-node step of hitBVH (two child boxes, f5:282-307)
-//   OP_LEAF  one triangle of hitArray (f5:247-254)
-//   OP_A     the primary ray came back   (f5:940-951)
-//   OP_C     the env-visibility ray came back / was skipped, then BRDF sampling (f5:869-895)      [chap5 only]
-//   OP_D     the BRDF ray came back      (f5:896-920; f4:525-538; f3:391-412)
-// Each pass of the wave's single loop ballots the five populations, picks ONE op and executes it for every lane waiting
-// on it (persistent lanes; the ballot decides what runs, and parked lanes are refilled with their next ray by the
-// handler that serves them).  Cheap traversal steps keep running while lanes accumulate at the expensive handlers, so
-// each handler pass is executed by many lanes, whatever frame, bounce or ray kind each lane is in.  Per lane the sequence
-// of nodes, leaves, triangles, arithmetic and RNG calls is exactly the reference's.
+//   OP_LEAF  the triangles of the leaf it holds (hitArray, f5:243-256), served by the cooperative leaf pass
+//   OP_H     its ray came back: the shade pass (primary f5:940-951, env-visibility f5:869-895, BRDF ray f5:896-920 /
+//            f4:525-538 / f3:391-412, told apart by `kind`), which ends by emitting the lane's next ray
+// Each pass of the wave's single loop ballots the three populations, picks ONE op and executes it for every lane waiting
+// on it (persistent lanes; parked lanes are refilled with their next ray by the shade pass).  Cheap traversal steps keep
+// running while lanes accumulate at the expensive shade pass, so each shade pass is executed by many lanes, whatever
+// frame, bounce or ray kind each lane is in.  Per lane the sequence of nodes, leaves, triangles, arithmetic and RNG
+// calls is exactly the reference's.
 enum LaneOp { OP_INT = 0, OP_LEAF = 1, OP_H = 2, OP_DONE = 3 };
 enum RayKind { K_PRIMARY = 0, K_SHADOW = 1, K_BOUNCE = 2, K_NONE = 3 };
 
@@ -348,8 +355,20 @@ __device__ __forceinline__ int wstack_pop(const int* lds, const int* spill, long
     return spill[(long long)(sp - kLdsDepth) * stride];
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave (all lanes active): four DPP row shifts inside each 16-lane row, then
+// the two row broadcasts of gfx9 (lane 15 of a row into the next row; lane 31 into rows 2 and 3).
+__device__ __forceinline__ int wave_inclusive_sum(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 template <int MODE, bool STATS, bool SPILL>
-__global__ void __launch_bounds__(kWave) render_kernel(const RenderParams P) {
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU))) render_kernel(const RenderParams P) {
     __shared__ int s_stack[kLdsDepth * kWave];        // per-lane traversal stacks, [depth][lane]
     __shared__ float4 s_ray[2 * kWave];                // per-lane ray in flight: (S.xyz, d.x) (d.yz, -, -)
     __shared__ int s_item[kWave];                      // cooperative leaf pass: item -> (triangle << 6 | owner lane)
@@ -622,11 +641,7 @@ __global__ void __launch_bounds__(kWave) render_kernel(const RenderParams P) {
             const bool leaf = (op == OP_LEAF);
             const int end = (cur & 0x00ffffff) + ((cur >> 24) & 0x7f) + 1;
             const int rem = leaf ? (end - ti) : 0;
-            int incl = rem;  // inclusive prefix sum over the wave
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += v;
-            }
+            const int incl = wave_inclusive_sum(rem);
             const int start = incl - rem;
             int serve = 64 - start;
             serve = serve < 0 ? 0 : (serve > rem ? rem : serve);

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'/root/repo')
+import sys; import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import ray_tracing_amd as rt
 from ray_tracing_amd import scenes
 t,n=scenes.chap5_scene(); hdr,cache=scenes.hdr_and_cache()
@@ -6,4 +6,4 @@ sc=rt.Scene(t,n,hdr,cache,device=0)
 eye,cam=rt.camera(0,20,4)
 d=rt.make_desc(1920,1080,mode=5,eye=eye,camera_rotate=cam)
 st=sc.render_stats(d,16,16); print(st)
-print("waves",(1920//16)*((1080+15)//16)*4)
+print("waves", ((1920 + 7) // 8) * ((1080 + 7) // 8))
