@@ -51,6 +51,11 @@ __device__ const unsigned d_sobolV[8 * 32] = {
     2147483648u, 3221225472u, 2684354560u, 3489660928u, 1476395008u, 2483027968u, 1040187392u, 3808428032u, 3196059648u, 599785472u, 505413632u, 4077912064u, 1182269440u, 1736704000u, 2017853440u, 2221342720u, 3329785856u, 2810494976u, 3628507136u, 1416089600u, 2658719744u, 864310272u, 3863387648u, 3076993792u, 553150080u, 272922560u, 4167467040u, 1148698640u, 1719673080u, 2009075780u, 2149644390u, 3222291575u,
     2147483648u, 1073741824u, 2684354560u, 1342177280u, 2281701376u, 1946157056u, 436207616u, 2566914048u, 2625634304u, 3208642560u, 2720006144u, 2098200576u, 111673344u, 2354315264u, 3464626176u, 4027383808u, 2886631424u, 3770826752u, 1691164672u, 3357462528u, 1993345024u, 3752330240u, 873073152u, 2870150400u, 1700563072u, 87021376u, 1097028000u, 1222351248u, 1560027592u, 2977959924u, 23268898u, 437609937u};
 
+#ifdef RT_OP_CYCLES
+// profiling builds only (-DRT_OP_CYCLES): s_memtime ticks spent in each kind of pass, summed over waves
+__device__ unsigned long long g_opcycles[8];
+#endif
+
 // ---- device view of a scene ------------------------------------------------------------------------------------
 struct DevScene {
     const float4* ttri;   // 3 x float4 per triangle: (p1.xyz,p2.x) (p2.yz,p3.xy) (p3.z,N.xyz)
@@ -77,6 +82,8 @@ struct RenderParams {
     float eye[3];
     float cam[16];
     float* accum;
+    float* samples;        // per wave: radiance samples of the current frame chunk, [frame in chunk][pixel in tile][3]
+    int chunk_frames;      // frames per chunk
     int* spill;            // global stack spill, [depth - kLdsDepth][thread]
     long long spill_stride;
     unsigned long long* stats;  // 6 counters (STATS builds)
@@ -340,6 +347,8 @@ __device__ __forceinline__ bool finite3(vec3 v) {
 }
 
 constexpr int kWave = 64;         // render_kernel: one wave64 per workgroup, an 8x8 pixel tile
+constexpr int kChunkFrames = 32;   // frames per chunk of the path loop (sample buffer = 768 B x frames per wave)
+constexpr size_t kMaxSampleBytes = (size_t)4 << 30;
 constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
 
 template <bool SPILL>
@@ -374,30 +383,34 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     __shared__ int s_item[kWave];                      // cooperative leaf pass: item -> (triangle << 6 | owner lane)
     __shared__ unsigned long long s_key[kWave];        // per owner: min over its items of (t bits << 32 | triangle)
     __shared__ float s_t[kWave];                       // STATS builds: per item hit distance (INF = miss)
+    __shared__ float2 s_cp[kWave];                     // per pixel of the tile: Cranley-Patterson shift (f5:367-383)
     const DevScene& sc = P.sc;
     const int lane = threadIdx.x;
     const int tilesx = (P.width + 7) >> 3;
-    const int px = (blockIdx.x % tilesx) * 8 + (lane & 7), py = (blockIdx.x / tilesx) * 8 + (lane >> 3);
+    const int tx0 = (blockIdx.x % tilesx) * 8, ty0 = (blockIdx.x / tilesx) * 8;  // tile origin
+    // lane l keeps the accumulator of pixel l of the tile; the SAMPLES of the tile are handed to whichever lane is free
+    const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
     const bool active = px < P.width && py < P.height;
     int* const stk_lds = &s_stack[lane];
     int* const stk_spill = SPILL ? (P.spill + ((long long)blockIdx.x * kWave + lane)) : nullptr;
     const long long stk_stride = P.spill_stride;
+    float* const sbuf = P.samples + (size_t)blockIdx.x * P.chunk_frames * (kWave * 3);
     Stats st = {0, 0, 0, 0, 0};
     unsigned long long paths = 0;
     unsigned dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // STATS builds: passes / active-lane sums per op
 
-    // per-pixel constants: pix = quad position at the pixel centre (vshader.vsh:7-10), GL row order (row 0 = bottom)
-    const float pixx = -1.0f + 2.0f * ((float)px + 0.5f) / (float)P.width;
-    const float pixy = -1.0f + 2.0f * ((float)py + 0.5f) / (float)P.height;
-    float cpu = 0.0f, cpv = 0.0f;
-    if (MODE == RT_MODE_CHAP5) cp_shift(pixx, pixy, P.width, P.height, &cpu, &cpv);
-    float* out = P.accum + ((size_t)(active ? py : 0) * P.width + (active ? px : 0)) * 3;
-    vec3 acc = active ? v3(out[0], out[1], out[2]) : v3(0);
+    if (MODE == RT_MODE_CHAP5) {  // per-pixel constant, read back by whichever lane samples the pixel
+        const float pixx = -1.0f + 2.0f * ((float)px + 0.5f) / (float)P.width;
+        const float pixy = -1.0f + 2.0f * ((float)py + 0.5f) / (float)P.height;
+        float cpu, cpv;
+        cp_shift(pixx, pixy, P.width, P.height, &cpu, &cpv);
+        s_cp[lane] = make_float2(cpu, cpv);
+    }
 
     // lane state
     int op = OP_DONE;
     int kind = K_PRIMARY;
-    int f = 0;                      // frames done
+    int item = 0;                   // the sample this lane works on: (frame in chunk) << 6 | pixel in tile
     unsigned seed = 0;
     int bounce = 0;
     vec3 S = v3(0), d = v3(0, 0, 1), invdir = v3(0);  // ray in flight
@@ -410,9 +423,26 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     int first_tri = -1;             // triangle of the primary hit (Le), -1 = primary miss
     vec3 Lo = v3(0), history = v3(1);
 
-    bool need_new = active;         // start the first sample in the prologue pass
+#ifdef RT_OP_CYCLES
+    unsigned long long oc[4] = {0, 0, 0, 0};
+    const long long oc_begin = clock64();
+#endif
+  // Frames are processed in chunks.  Inside a chunk the tile's samples (pixel, frame) are independent work items, handed out
+  // in order to lanes as they become free, so a lane whose paths are short (sky) does not idle while its neighbours trace
+  // long ones.  Each sample goes to the chunk's sample buffer; at the end of the chunk lane l folds pixel l's samples into
+  // its accumulator in frame order, which keeps the fp32 running mean of f5:954-955 exact.
+  for (int c0 = 0; c0 < P.frame_count; c0 += P.chunk_frames) {
+    const int n_items = (P.frame_count - c0 < P.chunk_frames ? P.frame_count - c0 : P.chunk_frames) * kWave;
+    const unsigned frame0 = (unsigned)(P.frame_begin + c0);
+    int next_item = 0;              // wave-uniform: first sample not handed out yet
+    __syncthreads();                // s_cp written / previous chunk's fold has read the sample buffer
+    bool need_new = true;           // every lane asks for its first sample in the prologue pass
     int pick = OP_H;                // the prologue runs the shade pass once with no lane in OP_H: only its tail
     for (;;) {
+#ifdef RT_OP_CYCLES
+        const long long oc_t0 = clock64();
+        const int oc_pick = pick;
+#endif
         if (pick >= OP_H) {
             // ---- the shade pass: every lane whose ray came back (primary / env-visibility / BRDF ray, told apart by
             // `kind`), step by step; a step runs once for all lanes that need it ------------------------------------
@@ -524,12 +554,13 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             // ---- BRDF importance sampling (f5:883-895): after the env-visibility ray, or at once when it was skipped ---
             if (MODE == RT_MODE_CHAP5 && (isC || to_C)) {
                 const Mat mat = load_material(sc, surf_tri);
-                const unsigned frame = (unsigned)(P.frame_begin + f);
+                const unsigned frame = frame0 + (unsigned)(item >> 6);
                 const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
                 const float su = sobol_dim(d_sobolV, bounce * 2, gray);
                 const float sv = sobol_dim(d_sobolV, bounce * 2 + 1, gray);
-                const float xi_1 = cp_rotate(su, cpu);
-                const float xi_2 = cp_rotate(sv, cpv);
+                const float2 cp = s_cp[item & 63];
+                const float xi_1 = cp_rotate(su, cp.x);
+                const float xi_2 = cp_rotate(sv, cp.y);
                 const float xi_3 = rand01(seed);
                 const vec3 Ls = SampleBRDF(xi_1, xi_2, xi_3, V, N, mat);
                 if (dot(N, Ls) <= 0.0f) {
@@ -538,31 +569,41 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     S = hitP, d = Ls, kind = K_BOUNCE, emit = true;
                 }
             }
-            // ---- end of a sample: frame blend (f5:954-955) -------------------------------------------------------
+            // ---- end of a sample: Le + Li (f5:950) goes to the chunk's sample buffer -----------------------------------
             if (fin) {
                 vec3 sample = Lo;
                 if (first_tri >= 0) {
                     const float* T = sc.tris + (size_t)first_tri * 36 + 18;
-                    sample = v3(T[0], T[1], T[2]) + Lo;  // Le + Li, f5:950
+                    sample = v3(T[0], T[1], T[2]) + Lo;
                 }
-                const unsigned frame = (unsigned)(P.frame_begin + f);
-                if (P.accumulate == RT_ACCUM_SUM)
-                    acc = acc + sample;
-                else
-                    acc = mix3(acc, sample, 1.0f / (float)(int)(frame + 1u));
+                float* o = sbuf + item * 3;
+                o[0] = sample.x, o[1] = sample.y, o[2] = sample.z;
                 if (STATS) paths++;
-                f++;
                 need_new = true;
             }
-            // ---- next sample: seed, jitter, camera ray (f5:320-323, 932-937) -------------------------------------
+            // ---- next sample: hand out the chunk's remaining (frame, pixel) items in order; pixels outside the image are
+            // skipped.  Then seed, jitter, camera ray (f5:320-323, 932-937) ---------------------------------------------
+            bool got = false;
+            for (;;) {
+                const unsigned long long asking = __ballot(need_new && !got);
+                if (asking == 0ull || next_item >= n_items) break;  // wave-uniform
+                if (need_new && !got) {
+                    const int it = next_item + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(asking >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)asking, 0u));
+                    if (it < n_items) {
+                        item = it;
+                        got = (tx0 + (it & 7) < P.width) && (ty0 + ((it >> 3) & 7) < P.height);
+                    }
+                }
+                next_item += __popcll(asking);
+            }
             if (need_new) {
                 need_new = false;
-                if (f >= P.frame_count) {
-                    op = OP_DONE;
-                    out[0] = acc.x, out[1] = acc.y, out[2] = acc.z;
+                if (!got) {
+                    op = OP_DONE;  // nothing left in this chunk
                 } else {
-                    const unsigned frame = (unsigned)(P.frame_begin + f);
-                    seed = pixel_seed(pixx, pixy, P.width, P.height, frame);
+                    const float pixx = -1.0f + 2.0f * ((float)(tx0 + (item & 7)) + 0.5f) / (float)P.width;
+                    const float pixy = -1.0f + 2.0f * ((float)(ty0 + ((item >> 3) & 7)) + 0.5f) / (float)P.height;
+                    seed = pixel_seed(pixx, pixy, P.width, P.height, frame0 + (unsigned)(item >> 6));
                     const float aax = (rand01(seed) - 0.5f) / (float)P.width;
                     const float aay = (rand01(seed) - 0.5f) / (float)P.height;
                     const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
@@ -701,6 +742,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (STATS && lane == 0) dg[10]++, dg[11] += n_items;
         }
 
+#ifdef RT_OP_CYCLES
+        oc[oc_pick > 2 ? 2 : oc_pick] += (unsigned long long)(clock64() - oc_t0);
+#endif
         // ---- scheduler: ballot the populations, pick the next op ---------------------------------------------------
         const int nI = __popcll(__ballot(op == OP_INT)), nL = __popcll(__ballot(op == OP_LEAF));
         const int nH = __popcll(__ballot(op == OP_H));
@@ -709,7 +753,35 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
         const int tb = (nL >= P.leaf_lanes || nI == 0) ? OP_LEAF : OP_INT, tn = nI + nL;
         pick = (tn == 0 || nH >= P.refill) ? OP_H : tb;
         if (STATS && lane == 0) dg[2 * pick]++, dg[2 * pick + 1] += (pick == OP_H) ? nH : ((pick == OP_INT) ? nI : nL);
+        if (STATS) {  // lanes that have finished all their frames and idle until the wave ends
+            const int nD = __popcll(__ballot(op == OP_DONE));
+            if (lane == 0) dg[6]++, dg[7] += nD;
+        }
     }
+    // ---- fold the chunk's samples into the accumulators, frame by frame (f5:954-955) ------------------------------------
+    __syncthreads();  // the samples were written by other lanes of this wave
+    if (active) {
+        float* out = P.accum + ((size_t)py * P.width + px) * 3;
+        vec3 acc = v3(out[0], out[1], out[2]);
+        for (int k = 0; k < n_items; k += kWave) {
+            const float* o = sbuf + (k + lane) * 3;
+            const vec3 sample = v3(o[0], o[1], o[2]);
+            const unsigned frame = frame0 + (unsigned)(k >> 6);
+            if (P.accumulate == RT_ACCUM_SUM)
+                acc = acc + sample;
+            else
+                acc = mix3(acc, sample, 1.0f / (float)(int)(frame + 1u));
+        }
+        out[0] = acc.x, out[1] = acc.y, out[2] = acc.z;
+    }
+  }
+#ifdef RT_OP_CYCLES
+    if (lane == 0) {
+        oc[3] = (unsigned long long)(clock64() - oc_begin);
+        for (int k = 0; k < 4; ++k) atomicAdd(&g_opcycles[k], oc[k]);
+        atomicAdd(&g_opcycles[4], 1ull);
+    }
+#endif
     if (STATS) {
         flush_stats(P, st, paths);
         if (lane == 0)
@@ -771,6 +843,8 @@ struct rt_scene {
     void* d_cache = nullptr;
     int* d_spill = nullptr;
     size_t spill_bytes = 0;
+    float* d_samples = nullptr;  // per-wave sample buffer of the path loop (one frame chunk)
+    size_t samples_bytes = 0;
 };
 
 static int f2i_checked(float f, int* out) {
@@ -796,7 +870,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_ttri), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
-    (void)hipFree(s->d_cache), (void)hipFree(s->d_spill);
+    (void)hipFree(s->d_cache), (void)hipFree(s->d_spill), (void)hipFree(s->d_samples);
     delete s;
 }
 
@@ -987,6 +1061,22 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
     P.max_bounce = d->max_bounce > 0 ? d->max_bounce : (d->mode == RT_MODE_CHAP5 ? 4 : 6);
     P.frame_begin = frame_begin, P.frame_count = frame_count;
     P.accum = accum_dev;
+    {   // sample buffer: blocks x chunk_frames x 64 pixels x RGB fp32, kept with the scene and grown on demand
+        int chunk = kChunkFrames;
+        if (const char* e = getenv("RT_AMD_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : kChunkFrames;  // tuning knob
+        if (chunk > frame_count) chunk = frame_count;
+        const size_t per_frame = (size_t)blocks * kWave * 3 * sizeof(float);
+        while (chunk > 1 && per_frame * chunk > kMaxSampleBytes) chunk >>= 1;
+        const size_t bytes = per_frame * chunk;
+        if (bytes > s->samples_bytes) {
+            (void)hipFree(s->d_samples);
+            s->d_samples = nullptr, s->samples_bytes = 0;
+            if (hipMalloc((void**)&s->d_samples, bytes) != hipSuccess)
+                return set_error(RT_ERR_OOM, "rt_render: cannot allocate the %zu-byte sample buffer", bytes);
+            s->samples_bytes = bytes;
+        }
+        P.samples = s->d_samples, P.chunk_frames = chunk;
+    }
     P.stats = stats_dev;
     const bool spill = P.spill != nullptr;
     TimedLaunch tl;
@@ -1071,7 +1161,7 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_render_stats: %s", hipGetErrorString(e));
     if (getenv("RT_AMD_DIAG")) {
-        static const char* nm[6] = {"OP_INT", "OP_LEAF (lanes)", "OP_H(shade)", "-", "-", "leaf items"};
+        static const char* nm[6] = {"OP_INT", "OP_LEAF (lanes)", "OP_H(shade)", "all passes: DONE", "-", "leaf items"};
         for (int k = 0; k < 6; ++k)
             fprintf(stderr, "[rt diag] %-18s wave passes %llu, mean active lanes %.1f\n", nm[k], h[6 + 2 * k], h[6 + 2 * k] ? (double)h[7 + 2 * k] / (double)h[6 + 2 * k] : 0.0);
     }
@@ -1140,6 +1230,18 @@ int rt_kernel_time_ms(float* avg_ms, int* launches, int reset) {
     }
     if (avg_ms) *avg_ms = n ? (float)(total / n) : 0.0f;
     if (launches) *launches = n;
+#ifdef RT_OP_CYCLES
+    {
+        unsigned long long h[8] = {0}, z[8] = {0};
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_opcycles), sizeof(h)) == hipSuccess && h[4]) {
+            const double tot = (double)h[3];
+            fprintf(stderr, "[rt cycles] waves %llu, ticks/wave %.0f: INT %.1f%%  LEAF %.1f%%  shade %.1f%%  scheduler+prologue %.1f%%\n", h[4],
+                    tot / (double)h[4], 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot,
+                    100.0 * (tot - h[0] - h[1] - h[2]) / tot);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_opcycles), z, sizeof(z));
+        }
+    }
+#endif
     if (reset) {
         for (auto& tl : g_launches) (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
         g_launches.clear();
