@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=16, help="frames (samples per pixel) per step per GPU")
+    ap.add_argument("--spp", type=int, default=32, help="frames (samples per pixel) per step per GPU")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--mode", type=int, default=5, choices=[3, 4, 5])
@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--up-angle", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
-    ap.add_argument("--cpu-sample", default="1920x1080x32", help="WxHxSPP sample of the same workload for the CPU oracle")
+    ap.add_argument("--cpu-sample", default="1920x1080x128", help="WxHxSPP sample of the same workload for the CPU oracle")
     args = ap.parse_args()
 
     import numpy as np

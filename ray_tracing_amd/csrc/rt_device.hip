@@ -329,7 +329,7 @@ __device__ __forceinline__ void flush_stats(const RenderParams& P, const Stats& 
 enum LaneOp { OP_INT = 0, OP_LEAF = 1, OP_H = 2, OP_DONE = 3 };
 enum RayKind { K_PRIMARY = 0, K_SHADOW = 1, K_BOUNCE = 2, K_NONE = 3 };
 
-constexpr int kHandlerLanes = 40;  // run a handler once this many lanes wait for it (or nothing is traversing)
+constexpr int kHandlerLanes = 48;  // run a handler once this many lanes wait for it (or nothing is traversing)
 
 // hitAABB (f5:225-238) with hardware min/max.  Equal to the ternary form whenever no operand is NaN (the results are
 // only compared, so the sign of a zero does not matter); rays that can produce NaN (a zero/NaN direction component or a
