@@ -82,8 +82,9 @@ struct RenderParams {
     float eye[3];
     float cam[16];
     float* accum;
-    float* samples;        // per wave: radiance samples of the current frame chunk, [frame in chunk][pixel in tile][3]
-    int chunk_frames;      // frames per chunk
+    float* samples;        // radiance samples of this launch, [frame - frame_begin][pixel][3]
+    unsigned* queue;       // work queue: the next unit (tile, frame group) to hand to a wave
+    int unit_frames;       // frames per unit
     int* spill;            // global stack spill, [depth - kLdsDepth][thread]
     long long spill_stride;
     unsigned long long* stats;  // 6 counters (STATS builds)
@@ -347,7 +348,8 @@ __device__ __forceinline__ bool finite3(vec3 v) {
 }
 
 constexpr int kWave = 64;         // render_kernel: one wave64 per workgroup, an 8x8 pixel tile
-constexpr int kChunkFrames = 32;   // frames per chunk of the path loop (sample buffer = 768 B x frames per wave)
+constexpr int kLaunchFrames = 32;  // frames per kernel launch (sample buffer = W x H x frames x 12 B)
+constexpr int kUnitFrames = 8;     // frames per work unit (one 8x8 tile x this many frames = 512 samples)
 constexpr size_t kMaxSampleBytes = (size_t)4 << 30;
 constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
 
@@ -383,34 +385,24 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     __shared__ int s_item[kWave];                      // cooperative leaf pass: item -> (triangle << 6 | owner lane)
     __shared__ unsigned long long s_key[kWave];        // per owner: min over its items of (t bits << 32 | triangle)
     __shared__ float s_t[kWave];                       // STATS builds: per item hit distance (INF = miss)
-    __shared__ float2 s_cp[kWave];                     // per pixel of the tile: Cranley-Patterson shift (f5:367-383)
     const DevScene& sc = P.sc;
     const int lane = threadIdx.x;
-    const int tilesx = (P.width + 7) >> 3;
-    const int tx0 = (blockIdx.x % tilesx) * 8, ty0 = (blockIdx.x / tilesx) * 8;  // tile origin
-    // lane l keeps the accumulator of pixel l of the tile; the SAMPLES of the tile are handed to whichever lane is free
-    const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
-    const bool active = px < P.width && py < P.height;
+    const int tilesx = (P.width + 7) >> 3, n_tiles = tilesx * ((P.height + 7) >> 3);
+    const int n_units = n_tiles * ((P.frame_count + P.unit_frames - 1) / P.unit_frames);
+    const size_t n_pixels = (size_t)P.width * P.height;
     int* const stk_lds = &s_stack[lane];
     int* const stk_spill = SPILL ? (P.spill + ((long long)blockIdx.x * kWave + lane)) : nullptr;
     const long long stk_stride = P.spill_stride;
-    float* const sbuf = P.samples + (size_t)blockIdx.x * P.chunk_frames * (kWave * 3);
     Stats st = {0, 0, 0, 0, 0};
     unsigned long long paths = 0;
     unsigned dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // STATS builds: passes / active-lane sums per op
 
-    if (MODE == RT_MODE_CHAP5) {  // per-pixel constant, read back by whichever lane samples the pixel
-        const float pixx = -1.0f + 2.0f * ((float)px + 0.5f) / (float)P.width;
-        const float pixy = -1.0f + 2.0f * ((float)py + 0.5f) / (float)P.height;
-        float cpu, cpv;
-        cp_shift(pixx, pixy, P.width, P.height, &cpu, &cpv);
-        s_cp[lane] = make_float2(cpu, cpv);
-    }
-
     // lane state
     int op = OP_DONE;
     int kind = K_PRIMARY;
-    int item = 0;                   // the sample this lane works on: (frame in chunk) << 6 | pixel in tile
+    int pxy = 0;                    // the sample this lane works on: pixel (px | py << 16) ...
+    int fidx = 0;                   // ... and frame, counted from frame_begin
+    float cpu = 0.0f, cpv = 0.0f;   // Cranley-Patterson shift of that pixel (f5:367-383)
     unsigned seed = 0;
     int bounce = 0;
     vec3 S = v3(0), d = v3(0, 0, 1), invdir = v3(0);  // ray in flight
@@ -427,15 +419,14 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     unsigned long long oc[4] = {0, 0, 0, 0};
     const long long oc_begin = clock64();
 #endif
-  // Frames are processed in chunks.  Inside a chunk the tile's samples (pixel, frame) are independent work items, handed out
-  // in order to lanes as they become free, so a lane whose paths are short (sky) does not idle while its neighbours trace
-  // long ones.  Each sample goes to the chunk's sample buffer; at the end of the chunk lane l folds pixel l's samples into
-  // its accumulator in frame order, which keeps the fp32 running mean of f5:954-955 exact.
-  for (int c0 = 0; c0 < P.frame_count; c0 += P.chunk_frames) {
-    const int n_items = (P.frame_count - c0 < P.chunk_frames ? P.frame_count - c0 : P.chunk_frames) * kWave;
-    const unsigned frame0 = (unsigned)(P.frame_begin + c0);
-    int next_item = 0;              // wave-uniform: first sample not handed out yet
-    __syncthreads();                // s_cp written / previous chunk's fold has read the sample buffer
+    // The launch's samples (pixel, frame) are independent work items.  They are grouped in units (one 8x8 tile x
+    // unit_frames frames) behind one global counter; a wave takes a unit, hands its items in order to lanes as they become
+    // free, and takes the next unit while its last paths are still in flight — so no lane waits for a neighbour's longer
+    // path and every wave runs until the queue is empty.  Samples go to the launch's sample buffer; fold_kernel then
+    // applies f5:954-955 per pixel in frame order, which keeps the fp32 running mean exact.
+    int unit_tx0 = 0, unit_ty0 = 0, unit_f0 = 0;  // wave-uniform: the unit being handed out
+    int unit_items = 0, next_item = 0;            // its size and the first item not handed out yet
+    bool queue_empty = false;
     bool need_new = true;           // every lane asks for its first sample in the prologue pass
     int pick = OP_H;                // the prologue runs the shade pass once with no lane in OP_H: only its tail
     for (;;) {
@@ -554,13 +545,12 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             // ---- BRDF importance sampling (f5:883-895): after the env-visibility ray, or at once when it was skipped ---
             if (MODE == RT_MODE_CHAP5 && (isC || to_C)) {
                 const Mat mat = load_material(sc, surf_tri);
-                const unsigned frame = frame0 + (unsigned)(item >> 6);
+                const unsigned frame = (unsigned)(P.frame_begin + fidx);
                 const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
                 const float su = sobol_dim(d_sobolV, bounce * 2, gray);
                 const float sv = sobol_dim(d_sobolV, bounce * 2 + 1, gray);
-                const float2 cp = s_cp[item & 63];
-                const float xi_1 = cp_rotate(su, cp.x);
-                const float xi_2 = cp_rotate(sv, cp.y);
+                const float xi_1 = cp_rotate(su, cpu);
+                const float xi_2 = cp_rotate(sv, cpv);
                 const float xi_3 = rand01(seed);
                 const vec3 Ls = SampleBRDF(xi_1, xi_2, xi_3, V, N, mat);
                 if (dot(N, Ls) <= 0.0f) {
@@ -569,29 +559,45 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     S = hitP, d = Ls, kind = K_BOUNCE, emit = true;
                 }
             }
-            // ---- end of a sample: Le + Li (f5:950) goes to the chunk's sample buffer -----------------------------------
+            // ---- end of a sample: Le + Li (f5:950) goes to the launch's sample buffer ----------------------------------
             if (fin) {
                 vec3 sample = Lo;
                 if (first_tri >= 0) {
                     const float* T = sc.tris + (size_t)first_tri * 36 + 18;
                     sample = v3(T[0], T[1], T[2]) + Lo;
                 }
-                float* o = sbuf + item * 3;
+                float* o = P.samples + ((size_t)fidx * n_pixels + (size_t)(pxy >> 16) * P.width + (pxy & 0xffff)) * 3;
                 o[0] = sample.x, o[1] = sample.y, o[2] = sample.z;
                 if (STATS) paths++;
                 need_new = true;
             }
-            // ---- next sample: hand out the chunk's remaining (frame, pixel) items in order; pixels outside the image are
-            // skipped.  Then seed, jitter, camera ray (f5:320-323, 932-937) ---------------------------------------------
+            // ---- next sample: hand out the unit's remaining (frame, pixel) items in order, taking the next unit from the
+            // queue when it runs out; pixels outside the image are skipped.  Then seed, jitter, camera ray (f5:320-323,
+            // 932-937) --------------------------------------------------------------------------------------------------
             bool got = false;
             for (;;) {
                 const unsigned long long asking = __ballot(need_new && !got);
-                if (asking == 0ull || next_item >= n_items) break;  // wave-uniform
+                if (asking == 0ull) break;  // wave-uniform
+                if (next_item >= unit_items) {
+                    if (queue_empty) break;
+                    unsigned u = 0;
+                    if (lane == 0) u = __hip_atomic_fetch_add(P.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    u = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
+                    if (u >= (unsigned)n_units) {
+                        queue_empty = true;
+                        break;
+                    }
+                    const int tile = (int)u % n_tiles, group = (int)u / n_tiles;  // all tiles of a frame group, then the next group
+                    unit_tx0 = (tile % tilesx) * 8, unit_ty0 = (tile / tilesx) * 8, unit_f0 = group * P.unit_frames;
+                    const int nf = P.frame_count - unit_f0 < P.unit_frames ? P.frame_count - unit_f0 : P.unit_frames;
+                    unit_items = nf * kWave, next_item = 0;
+                }
                 if (need_new && !got) {
                     const int it = next_item + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(asking >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)asking, 0u));
-                    if (it < n_items) {
-                        item = it;
-                        got = (tx0 + (it & 7) < P.width) && (ty0 + ((it >> 3) & 7) < P.height);
+                    if (it < unit_items) {
+                        const int ix = unit_tx0 + (it & 7), iy = unit_ty0 + ((it >> 3) & 7);
+                        pxy = ix | (iy << 16), fidx = unit_f0 + (it >> 6);
+                        got = ix < P.width && iy < P.height;
                     }
                 }
                 next_item += __popcll(asking);
@@ -599,11 +605,12 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (need_new) {
                 need_new = false;
                 if (!got) {
-                    op = OP_DONE;  // nothing left in this chunk
+                    op = OP_DONE;  // the queue is empty
                 } else {
-                    const float pixx = -1.0f + 2.0f * ((float)(tx0 + (item & 7)) + 0.5f) / (float)P.width;
-                    const float pixy = -1.0f + 2.0f * ((float)(ty0 + ((item >> 3) & 7)) + 0.5f) / (float)P.height;
-                    seed = pixel_seed(pixx, pixy, P.width, P.height, frame0 + (unsigned)(item >> 6));
+                    const float pixx = -1.0f + 2.0f * ((float)(pxy & 0xffff) + 0.5f) / (float)P.width;
+                    const float pixy = -1.0f + 2.0f * ((float)(pxy >> 16) + 0.5f) / (float)P.height;
+                    if (MODE == RT_MODE_CHAP5) cp_shift(pixx, pixy, P.width, P.height, &cpu, &cpv);
+                    seed = pixel_seed(pixx, pixy, P.width, P.height, (unsigned)(P.frame_begin + fidx));
                     const float aax = (rand01(seed) - 0.5f) / (float)P.width;
                     const float aay = (rand01(seed) - 0.5f) / (float)P.height;
                     const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
@@ -758,23 +765,6 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (lane == 0) dg[6]++, dg[7] += nD;
         }
     }
-    // ---- fold the chunk's samples into the accumulators, frame by frame (f5:954-955) ------------------------------------
-    __syncthreads();  // the samples were written by other lanes of this wave
-    if (active) {
-        float* out = P.accum + ((size_t)py * P.width + px) * 3;
-        vec3 acc = v3(out[0], out[1], out[2]);
-        for (int k = 0; k < n_items; k += kWave) {
-            const float* o = sbuf + (k + lane) * 3;
-            const vec3 sample = v3(o[0], o[1], o[2]);
-            const unsigned frame = frame0 + (unsigned)(k >> 6);
-            if (P.accumulate == RT_ACCUM_SUM)
-                acc = acc + sample;
-            else
-                acc = mix3(acc, sample, 1.0f / (float)(int)(frame + 1u));
-        }
-        out[0] = acc.x, out[1] = acc.y, out[2] = acc.z;
-    }
-  }
 #ifdef RT_OP_CYCLES
     if (lane == 0) {
         oc[3] = (unsigned long long)(clock64() - oc_begin);
@@ -787,6 +777,26 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
         if (lane == 0)
             for (int k = 0; k < 12; ++k) atomicAdd(&P.stats[6 + k], (unsigned long long)dg[k]);
     }
+}
+
+// The frame blend of f5:954-955 (or the plain sum of the spp-split multi-GPU mode): per pixel, over the launch's samples
+// in frame order.
+__global__ void __launch_bounds__(256) fold_kernel(const RenderParams P) {
+    const size_t n_pixels = (size_t)P.width * P.height;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pixels) return;
+    float* out = P.accum + p * 3;
+    vec3 acc = v3(out[0], out[1], out[2]);
+    for (int k = 0; k < P.frame_count; ++k) {
+        const float* o = P.samples + ((size_t)k * n_pixels + p) * 3;
+        const vec3 sample = v3(o[0], o[1], o[2]);
+        const unsigned frame = (unsigned)(P.frame_begin + k);
+        if (P.accumulate == RT_ACCUM_SUM)
+            acc = acc + sample;
+        else
+            acc = mix3(acc, sample, 1.0f / (float)(int)(frame + 1u));
+    }
+    out[0] = acc.x, out[1] = acc.y, out[2] = acc.z;
 }
 
 // config 2: un-jittered camera rays, chapter-2 closest hit (c2:490-513)
@@ -843,8 +853,10 @@ struct rt_scene {
     void* d_cache = nullptr;
     int* d_spill = nullptr;
     size_t spill_bytes = 0;
-    float* d_samples = nullptr;  // per-wave sample buffer of the path loop (one frame chunk)
+    float* d_samples = nullptr;  // sample buffer of the path loop (one launch: W x H x frames x RGB)
     size_t samples_bytes = 0;
+    unsigned* d_queue = nullptr; // work-queue counter of the path loop
+    int cu_count = 0;
 };
 
 static int f2i_checked(float f, int* out) {
@@ -870,7 +882,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_ttri), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
-    (void)hipFree(s->d_cache), (void)hipFree(s->d_spill), (void)hipFree(s->d_samples);
+    (void)hipFree(s->d_cache), (void)hipFree(s->d_spill), (void)hipFree(s->d_samples), (void)hipFree(s->d_queue);
     delete s;
 }
 
@@ -964,6 +976,8 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
         if (e_ != hipSuccess) return fail(set_error(RT_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__)); \
     } while (0)
     HIPCHK_S(hipSetDevice(s->device));
+    HIPCHK_S(hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, s->device));
+    HIPCHK_S(hipMalloc((void**)&s->d_queue, 256));
     if (nT > 0) {
         HIPCHK_S(hipMalloc(&s->d_ttri, ttri.size() * 4));
         HIPCHK_S(hipMemcpy(s->d_ttri, ttri.data(), ttri.size() * 4, hipMemcpyHostToDevice));
@@ -1017,9 +1031,11 @@ static int fill_params(rt_scene* s, const rt_render_desc* d, RenderParams* P, in
     P->accumulate = d->accumulate;
     memcpy(P->eye, d->eye, sizeof(P->eye));
     memcpy(P->cam, d->camera_rotate, sizeof(P->cam));
-    // render_kernel: one wave64 per 8x8 tile; primary_kernel: 256 threads per 16x16 tile
-    const int tile = render ? 8 : 16, block_threads = render ? kWave : kBlock;
-    *blocks = ((d->width + tile - 1) / tile) * ((d->height + tile - 1) / tile);
+    // render_kernel: persistent single-wave workgroups, as many as the device can hold (32 wave slots per CU is the
+    // hardware ceiling; workgroups beyond the kernel's real occupancy start late, find the queue empty and leave);
+    // primary_kernel: 256 threads per 16x16 tile
+    const int block_threads = render ? kWave : kBlock;
+    *blocks = render ? s->cu_count * 32 : ((d->width + 15) / 16) * ((d->height + 15) / 16);
     P->leaf_lanes = kLeafLanes;
     if (const char* e = getenv("RT_AMD_LEAF")) P->leaf_lanes = atoi(e) > 0 ? atoi(e) : kLeafLanes;  // tuning knob
     P->refill = kHandlerLanes;
@@ -1059,50 +1075,61 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
     rc = fill_params(s, d, &P, &blocks, true);
     if (rc != RT_OK) return rc;
     P.max_bounce = d->max_bounce > 0 ? d->max_bounce : (d->mode == RT_MODE_CHAP5 ? 4 : 6);
-    P.frame_begin = frame_begin, P.frame_count = frame_count;
     P.accum = accum_dev;
-    {   // sample buffer: blocks x chunk_frames x 64 pixels x RGB fp32, kept with the scene and grown on demand
-        int chunk = kChunkFrames;
-        if (const char* e = getenv("RT_AMD_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : kChunkFrames;  // tuning knob
-        if (chunk > frame_count) chunk = frame_count;
-        const size_t per_frame = (size_t)blocks * kWave * 3 * sizeof(float);
-        while (chunk > 1 && per_frame * chunk > kMaxSampleBytes) chunk >>= 1;
-        const size_t bytes = per_frame * chunk;
-        if (bytes > s->samples_bytes) {
-            (void)hipFree(s->d_samples);
-            s->d_samples = nullptr, s->samples_bytes = 0;
-            if (hipMalloc((void**)&s->d_samples, bytes) != hipSuccess)
-                return set_error(RT_ERR_OOM, "rt_render: cannot allocate the %zu-byte sample buffer", bytes);
-            s->samples_bytes = bytes;
-        }
-        P.samples = s->d_samples, P.chunk_frames = chunk;
-    }
     P.stats = stats_dev;
+    P.queue = s->d_queue;
+    P.unit_frames = kUnitFrames;
+    if (const char* e = getenv("RT_AMD_UNIT")) P.unit_frames = atoi(e) > 0 ? atoi(e) : kUnitFrames;  // tuning knob
+    // frames per kernel launch: bounded by the sample buffer (W x H x frames x RGB fp32, kept with the scene)
+    int launch_frames = kLaunchFrames;
+    if (const char* e = getenv("RT_AMD_CHUNK")) launch_frames = atoi(e) > 0 ? atoi(e) : kLaunchFrames;  // tuning knob
+    if (launch_frames > frame_count) launch_frames = frame_count;
+    const size_t per_frame = (size_t)d->width * d->height * 3 * sizeof(float);
+    while (launch_frames > 1 && per_frame * launch_frames > kMaxSampleBytes) launch_frames >>= 1;
+    if (per_frame * launch_frames > s->samples_bytes) {
+        (void)hipFree(s->d_samples);
+        s->d_samples = nullptr, s->samples_bytes = 0;
+        if (hipMalloc((void**)&s->d_samples, per_frame * launch_frames) != hipSuccess)
+            return set_error(RT_ERR_OOM, "rt_render: cannot allocate the %zu-byte sample buffer", per_frame * launch_frames);
+        s->samples_bytes = per_frame * launch_frames;
+    }
+    P.samples = s->d_samples;
     const bool spill = P.spill != nullptr;
-    TimedLaunch tl;
-    HIPCHK(hipEventCreate(&tl.a));
-    HIPCHK(hipEventCreate(&tl.b));
-    HIPCHK(hipEventRecord(tl.a, stream));
-#define LAUNCH(MODE_)                                                                                   \
-    do {                                                                                                \
-        if (spill)                                                                                      \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, true>), dim3(blocks), dim3(kWave), 0, stream, P);  \
-        else                                                                                            \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, false>), dim3(blocks), dim3(kWave), 0, stream, P); \
+    const int n_tiles = ((d->width + 7) / 8) * ((d->height + 7) / 8);
+    const int fold_blocks = (int)(((size_t)d->width * d->height + 255) / 256);
+    for (int done = 0; done < frame_count; done += launch_frames) {
+        P.frame_begin = frame_begin + done;
+        P.frame_count = frame_count - done < launch_frames ? frame_count - done : launch_frames;
+        const long long n_units = (long long)n_tiles * ((P.frame_count + P.unit_frames - 1) / P.unit_frames);
+        const int grid = (int)(n_units < blocks ? n_units : blocks);  // persistent waves: at most what the device holds
+        HIPCHK(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned), stream));
+        TimedLaunch tl;
+        HIPCHK(hipEventCreate(&tl.a));
+        HIPCHK(hipEventCreate(&tl.b));
+        HIPCHK(hipEventRecord(tl.a, stream));
+#define LAUNCH(MODE_)                                                                                 \
+    do {                                                                                              \
+        if (spill)                                                                                    \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, true>), dim3(grid), dim3(kWave), 0, stream, P);  \
+        else                                                                                          \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, false>), dim3(grid), dim3(kWave), 0, stream, P); \
     } while (0)
-    if (d->mode == RT_MODE_CHAP5)
-        LAUNCH(RT_MODE_CHAP5);
-    else if (d->mode == RT_MODE_CHAP4)
-        LAUNCH(RT_MODE_CHAP4);
-    else
-        LAUNCH(RT_MODE_CHAP3);
+        if (d->mode == RT_MODE_CHAP5)
+            LAUNCH(RT_MODE_CHAP5);
+        else if (d->mode == RT_MODE_CHAP4)
+            LAUNCH(RT_MODE_CHAP4);
+        else
+            LAUNCH(RT_MODE_CHAP3);
 #undef LAUNCH
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(tl.b, stream));
-    if (!STATS)
-        g_launches.push_back(tl);
-    else {
-        (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(tl.b, stream));
+        if (!STATS)
+            g_launches.push_back(tl);
+        else {
+            (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
+        }
+        hipLaunchKernelGGL(fold_kernel, dim3(fold_blocks), dim3(256), 0, stream, P);
+        HIPCHK(hipGetLastError());
     }
     return RT_OK;
 }
