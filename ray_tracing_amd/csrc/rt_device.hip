@@ -349,7 +349,7 @@ __device__ __forceinline__ bool finite3(vec3 v) {
 
 constexpr int kWave = 64;         // render_kernel: one wave64 per workgroup, an 8x8 pixel tile
 constexpr int kLaunchFrames = 32;  // frames per kernel launch (sample buffer = W x H x frames x 12 B)
-constexpr int kUnitFrames = 8;     // frames per work unit (one 8x8 tile x this many frames = 512 samples)
+constexpr int kUnitFrames = 2;     // frames per work unit (one 8x8 tile x this many frames = 128 samples)
 constexpr size_t kMaxSampleBytes = (size_t)4 << 30;
 constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
 
