@@ -20,6 +20,17 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def _pmc_traffic(key):
+    """HBM bytes per launch of the path-loop kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, in
+    bytes; collected by tools/profile_round.sh, stored by hand in profiles/hbm_traffic.json).  None when this workload
+    was not profiled."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as f:
+            return json.load(f).get(key, {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +154,9 @@ def main():
             bytes_per_launch = bytes_per_ray * rays_per_path * paths_per_launch + 24.0 * W * H
             achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
             result["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": _pmc_traffic(f"{args.scene}_chap{args.mode}_{W}x{H}_spp{spp}"),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel": f"render_kernel<chap{args.mode}>", "kernel_ms": kern_ms, "launches": launches,
                 "bytes_per_ray": bytes_per_ray, "rays_per_path": rays_per_path,
                 "per_ray": {"I": I, "Lf": Lf, "T": T, "H": Hh},
