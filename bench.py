@@ -162,7 +162,7 @@ def main():
                 "per_ray": {"I": I, "Lf": Lf, "T": T, "H": Hh},
                 "valu": {"achieved_tflops": flops_per_ray * rays_per_path * paths_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
                          "peak_tflops_no_fma": 78.6},
-                "note": "scene (3.1 MB) is L2/Infinity-Cache resident: HBM is not the binding resource; see DESIGN.md",
+                "note": f"scene arrays {(tris.nbytes + nodes.nbytes) / 1e6:.1f} MB; the path loop is VALU-issue-bound, HBM is not the binding resource: see DESIGN.md section 5",
             }
             result["mrays_per_s_per_gpu"] = result["value"] * rays_per_path / world
         if not args.no_cpu_baseline:

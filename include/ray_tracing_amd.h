@@ -97,6 +97,17 @@ int rt_write_png(const char* path, int width, int height, const unsigned char* i
 
 void rt_free(void* p);
 
+/* On-disk scene cache (no counterpart in the reference, which rebuilds its BVH at every start, c5:843).
+ * The file holds the two arrays the reference uploads — Triangle_encoded[] (c5:54-64) in its final permuted order and
+ * BVHNode_encoded[] (c5:65-70) — raw little-endian fp32 behind a 48-byte header (magic "RTAMDSC1", record sizes, `key`,
+ * counts, FNV-1a-64 of the payload).  `key` is the caller's hash of whatever the arrays were built from (OBJ bytes,
+ * materials, transforms, leaf size): rt_scene_cache_load refuses a file whose key differs (RT_ERR_FORMAT), is truncated
+ * or whose payload hash is wrong.  Loaded arrays are released with rt_free.  rt_hash_fnv1a64(seed = 0) starts a hash;
+ * pass the previous result as `seed` to chain buffers. */
+uint64_t rt_hash_fnv1a64(const void* data, uint64_t n_bytes, uint64_t seed);
+int rt_scene_cache_save(const char* path, uint64_t key, const float* tris, int n_triangles, const float* nodes, int n_nodes);
+int rt_scene_cache_load(const char* path, uint64_t key, float** tris_out, int* n_triangles, float** nodes_out, int* n_nodes);
+
 /* Chapter 1 (config 1, host only): the CPU Cornell-box tracer of path_tracing_1chap/path_tracing.cpp — scene literal
  * c1:355-400, shoot c1:214-225, pathTracing c1:277-324, pixel loop c1:409-475 — race-free (one mt19937 per image row,
  * seeded from `seed`; the reference shares one generator between 50 threads).  `image` = W*H*3 doubles, row 0 = top

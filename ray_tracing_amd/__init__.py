@@ -96,6 +96,10 @@ _lib.rt_primary_hits.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, 
 _lib.rt_primary_hits_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
 _lib.rt_kernel_time_ms.argtypes = [_f32p, C.POINTER(C.c_int), C.c_int]
+_lib.rt_hash_fnv1a64.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+_lib.rt_hash_fnv1a64.restype = C.c_uint64
+_lib.rt_scene_cache_save.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+_lib.rt_scene_cache_load.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(_f32p), C.POINTER(C.c_int), C.POINTER(_f32p), C.POINTER(C.c_int)]
 
 
 def _check(rc: int):
@@ -303,3 +307,30 @@ def chap1_to_rgb8(image: np.ndarray) -> np.ndarray:
     out = np.empty(image.shape, np.uint8)
     _check(_lib.rt_chap1_to_rgb8(image.ctypes.data_as(C.c_void_p), image.shape[1], image.shape[0], out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def hash_fnv1a64(data, seed: int = 0) -> int:
+    """FNV-1a 64 of a bytes-like object or a C-contiguous array; pass the previous result as ``seed`` to chain."""
+    b = np.ascontiguousarray(data).view(np.uint8).reshape(-1) if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), np.uint8)
+    return int(_lib.rt_hash_fnv1a64(b.ctypes.data_as(C.c_void_p), b.size, seed))
+
+
+def scene_cache_save(path: str, key: int, triangles: np.ndarray, nodes: np.ndarray):
+    """Write Triangle_encoded[] + BVHNode_encoded[] (raw fp32) with ``key`` = hash of the inputs they were built from."""
+    t = np.ascontiguousarray(triangles, np.float32).reshape(-1, 36)
+    n = np.ascontiguousarray(nodes, np.float32).reshape(-1, 12)
+    _check(_lib.rt_scene_cache_save(os.fsencode(path), key, t.ctypes.data_as(C.c_void_p), t.shape[0],
+                                    n.ctypes.data_as(C.c_void_p), n.shape[0]))
+
+
+def scene_cache_load(path: str, key: int):
+    """(triangles, nodes) from a cache file; raises RtError if the file is missing, stale (other key) or corrupt."""
+    tp, np_ = _f32p(), _f32p()
+    nt, nn = C.c_int(0), C.c_int(0)
+    _check(_lib.rt_scene_cache_load(os.fsencode(path), key, C.byref(tp), C.byref(nt), C.byref(np_), C.byref(nn)))
+    try:
+        tris = np.ctypeslib.as_array(tp, shape=(nt.value, 36)).copy() if nt.value else np.zeros((0, 36), np.float32)
+        nodes = np.ctypeslib.as_array(np_, shape=(nn.value, 12)).copy() if nn.value else np.zeros((0, 12), np.float32)
+    finally:
+        _lib.rt_free(tp), _lib.rt_free(np_)
+    return tris, nodes

@@ -110,3 +110,24 @@ def synthetic_scene(n_objects: int = 64, subdiv: int = 32, seed: int = 0x5EED):
     mesh.readObj(_m("quad.obj"), m2, getTransformMatrix((0, 0, 0), (0, 0.2, 0), (18.83, 0.01, 18.83)), False)
     nodes = mesh.buildBVHwithSAH(8)
     return mesh.triangles(), nodes
+
+
+def cached_build(path: str, key: int, builder):
+    """SURVEY 8f-1: ``builder()`` -> (triangles, nodes) runs only when ``path`` is missing, stale (other ``key``) or corrupt;
+    otherwise the arrays come from the cache file (the reference's own layouts, raw fp32).  ``key`` = hash of the inputs,
+    e.g. ``rt.hash_fnv1a64(open(obj, 'rb').read(), rt.hash_fnv1a64(params_bytes))``."""
+    from . import RtError, scene_cache_load, scene_cache_save
+    try:
+        return scene_cache_load(path, key)
+    except RtError:
+        tris, nodes = builder()
+        scene_cache_save(path, key, tris, nodes)
+        return tris, nodes
+
+
+def synthetic_scene_cached(cache_dir: str, n_objects: int = 64, subdiv: int = 32, seed: int = 0x5EED):
+    """synthetic_scene behind the on-disk cache: the 10 M-triangle build (90 s) is paid once."""
+    from . import hash_fnv1a64
+    key = hash_fnv1a64(np.array([n_objects, subdiv, seed, 8], np.int64), hash_fnv1a64(open(_m("quad.obj"), "rb").read()))
+    path = os.path.join(cache_dir, f"synthetic_{n_objects}_{subdiv}_{seed:x}.rtsc")
+    return cached_build(path, key, lambda: synthetic_scene(n_objects, subdiv, seed))
