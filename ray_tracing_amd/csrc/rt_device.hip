@@ -396,6 +396,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     Stats st = {0, 0, 0, 0, 0};
     unsigned long long paths = 0;
     unsigned dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // STATS builds: passes / active-lane sums per op
+    unsigned sg[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // STATS builds: lanes taking each step of the shade pass
 
     // lane state
     int op = OP_DONE;
@@ -448,6 +449,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             vec3 f_r = v3(0);
             float pdf_brdf = 0.0f;
             const bool need_eval = isD || (h && kind == K_SHADOW && miss);
+            if (STATS) { const int c_ = __popcll(__ballot(need_eval)); if (lane == 0) sg[0] += c_; }
             if (need_eval) {
                 const Mat mat = load_material(sc, surf_tri);
                 if (MODE == RT_MODE_CHAP5) {
@@ -465,6 +467,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             const bool need_env = (isA && miss) || (h && kind == K_SHADOW && miss) || (d_alive && miss);
             vec3 color = v3(0);
             float pdf_light = 0.0f;
+            if (STATS) { const int c_ = __popcll(__ballot(need_env)); if (lane == 0) sg[1] += c_; }
             if (need_env) {
                 if (sc.hdr) {
                     float eu, ew;
@@ -502,6 +505,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 }
             }
             // step 4: the ray hit a surface: finish the hit record (smooth normal), move the path there
+            if (STATS) { const int c_ = __popcll(__ballot((isA || d_alive) && !miss)); if (lane == 0) sg[2] += c_; }
             if ((isA || d_alive) && !miss) {
                 const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
                 if (isD) {
@@ -527,6 +531,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 if (bounce < P.max_bounce) to_B = true; else fin = true;
             }
             // ---- start of a bounce (f5:856-866 env sample; chapters 3/4: the hemisphere sample) ------------------
+            if (STATS) { const int c_ = __popcll(__ballot(to_B)); if (lane == 0) sg[3] += c_; }
             if (to_B) {
                 if (MODE == RT_MODE_CHAP5) {
                     const float r1 = rand01(seed), r2 = rand01(seed);
@@ -543,6 +548,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 }
             }
             // ---- BRDF importance sampling (f5:883-895): after the env-visibility ray, or at once when it was skipped ---
+            if (STATS) { const int c_ = __popcll(__ballot(isC || to_C)); if (lane == 0) sg[4] += c_; }
             if (MODE == RT_MODE_CHAP5 && (isC || to_C)) {
                 const Mat mat = load_material(sc, surf_tri);
                 const unsigned frame = (unsigned)(P.frame_begin + fidx);
@@ -560,6 +566,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 }
             }
             // ---- end of a sample: Le + Li (f5:950) goes to the launch's sample buffer ----------------------------------
+            if (STATS) { const int c_ = __popcll(__ballot(fin)); if (lane == 0) sg[5] += c_; }
             if (fin) {
                 vec3 sample = Lo;
                 if (first_tri >= 0) {
@@ -623,6 +630,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 }
             }
             // ---- hitBVH prologue (f5:260-268) --------------------------------------------------------------------
+            if (STATS) { const int c_ = __popcll(__ballot(emit)); if (lane == 0) sg[6] += c_; }
             if (emit) {
                 if (STATS) st.rays++;
                 best = INF_, best_tri = -1, sp = 0, cur = sc.root_entry;
@@ -776,6 +784,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
         flush_stats(P, st, paths);
         if (lane == 0)
             for (int k = 0; k < 12; ++k) atomicAdd(&P.stats[6 + k], (unsigned long long)dg[k]);
+        if (lane == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[18 + k], (unsigned long long)sg[k]);
     }
 }
 
@@ -1173,10 +1183,10 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     float* dev = nullptr;
     unsigned long long* st = nullptr;
     HIPCHK(hipMalloc((void**)&dev, bytes));
-    hipError_t e = hipMalloc((void**)&st, 18 * sizeof(unsigned long long));
+    hipError_t e = hipMalloc((void**)&st, 26 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(dev, 0, bytes);
-    if (e == hipSuccess) e = hipMemset(st, 0, 18 * sizeof(unsigned long long));
-    unsigned long long h[18] = {0};
+    if (e == hipSuccess) e = hipMemset(st, 0, 26 * sizeof(unsigned long long));
+    unsigned long long h[26] = {0};
     if (e == hipSuccess) {
         rc = launch_render<true>(s, d, frame_begin, frame_count, dev, st, nullptr);
         if (rc == RT_OK) {
@@ -1188,6 +1198,9 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_render_stats: %s", hipGetErrorString(e));
     if (getenv("RT_AMD_DIAG")) {
+        static const char* sn[7] = {"BRDF eval", "env lookup", "finish hit", "bounce start", "BRDF sampling", "end of sample", "ray prologue"};
+        for (int k = 0; k < 7; ++k)
+            fprintf(stderr, "[rt diag] shade step %-14s mean lanes %.1f\n", sn[k], h[10] ? (double)h[18 + k] / (double)h[10] : 0.0);
         static const char* nm[6] = {"OP_INT", "OP_LEAF (lanes)", "OP_H(shade)", "all passes: DONE", "-", "leaf items"};
         for (int k = 0; k < 6; ++k)
             fprintf(stderr, "[rt diag] %-18s wave passes %llu, mean active lanes %.1f\n", nm[k], h[6 + 2 * k], h[6 + 2 * k] ? (double)h[7 + 2 * k] / (double)h[6 + 2 * k] : 0.0);

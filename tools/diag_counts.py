@@ -6,4 +6,3 @@ sc=rt.Scene(t,n,hdr,cache,device=0)
 eye,cam=rt.camera(0,20,4)
 d=rt.make_desc(1920,1080,mode=5,eye=eye,camera_rotate=cam)
 st=sc.render_stats(d,16,16); print(st)
-print("waves", ((1920 + 7) // 8) * ((1080 + 7) // 8))
