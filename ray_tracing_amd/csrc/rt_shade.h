@@ -200,6 +200,10 @@ RT_HD vec3 SampleGTR(float xi_1, float cos_theta_h, vec3 V, vec3 N) {  // common
     H = toNormalHemisphere(H, N);
     return reflect(-V, H);
 }
+// f5:575-608.  The three lobes (cosine hemisphere f5:524-535, GTR2 f5:556-573, GTR1 f5:537-554) are evaluated through ONE
+// shared sin/cos, square root, quotient and toNormalHemisphere, with the lobe selecting the operands: per lane every value
+// goes through exactly the operations of its own lobe's formula (SampleCosineHemisphere / SampleGTR above), so the result is
+// bit-identical to the branchy form, but a wave whose lanes picked different lobes runs the common part once, not three times.
 RT_HD vec3 SampleBRDF(float xi_1, float xi_2, float xi_3, vec3 V, vec3 N, const Mat& m) {
     const float alpha_GTR1 = mix_(0.1f, 0.001f, m.clearcoatGloss);
     const float alpha_GTR2 = fmax_(0.001f, sqr(m.roughness));
@@ -210,16 +214,26 @@ RT_HD vec3 SampleBRDF(float xi_1, float xi_2, float xi_3, vec3 V, vec3 N, const 
     const float p_diffuse = r_diffuse / r_sum;
     const float p_specular = r_specular / r_sum;
     const float rd = xi_3;
-    if (rd <= p_diffuse) {
-        return SampleCosineHemisphere(xi_1, xi_2, N);
-    } else if (p_diffuse < rd && rd <= p_diffuse + p_specular) {
-        const float c = sqrtf((1.0f - xi_2) / (1.0f + (alpha_GTR2 * alpha_GTR2 - 1.0f) * xi_2));
-        return SampleGTR(xi_1, c, V, N);
-    } else if (p_diffuse + p_specular < rd) {
-        const float c = sqrtf((1.0f - det_pow(alpha_GTR1 * alpha_GTR1, 1.0f - xi_2)) / (1.0f - alpha_GTR1 * alpha_GTR1));
-        return SampleGTR(xi_1, c, V, N);
+    const bool diffuse = rd <= p_diffuse;
+    const bool specular = !diffuse && (p_diffuse < rd && rd <= p_diffuse + p_specular);
+    const bool clearcoat = !diffuse && !specular && (p_diffuse + p_specular < rd);
+    if (!(diffuse || specular || clearcoat)) return v3(0, 1, 0);  // NaN weights
+    // cos(theta_h) of the two GTR lobes: sqrt(num / den)
+    float num = 1.0f - xi_2, den = 1.0f + (alpha_GTR2 * alpha_GTR2 - 1.0f) * xi_2;
+    if (clearcoat) {
+        num = 1.0f - det_pow(alpha_GTR1 * alpha_GTR1, 1.0f - xi_2);
+        den = 1.0f - alpha_GTR1 * alpha_GTR1;
     }
-    return v3(0, 1, 0);
+    const float cos_theta_h = sqrtf(num / den);
+    // the azimuth and the radial factor
+    const float angle = diffuse ? (xi_2 * 2.0f * PI_) : (2.0f * PI_ * xi_1);
+    const float radial = sqrtf(diffuse ? xi_1 : fmax_(0.0f, 1.0f - cos_theta_h * cos_theta_h));
+    const float sin_a = det_sin(angle), cos_a = det_cos(angle);
+    const float x = radial * cos_a;
+    const float y = radial * sin_a;
+    const float z = diffuse ? sqrtf(1.0f - x * x - y * y) : cos_theta_h;
+    const vec3 T = toNormalHemisphere(v3(x, y, z), N);
+    return diffuse ? T : reflect(-V, T);
 }
 
 // ---- E1/E2/S6: environment map, f5:612-660 -------------------------------------------------------------------------
