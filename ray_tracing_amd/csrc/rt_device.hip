@@ -41,7 +41,7 @@ constexpr int kLdsDepth = RT_LDS_DEPTH;    // per-lane stack entries kept in LDS
 constexpr int kMaxStack = 256;   // int stack[256], f5:265
 
 // Sobol direction numbers, f5:339 (data table: 8 dimensions x 32 bits)
-__device__ const unsigned d_sobolV[8 * 32] = {
+__device__ __align__(16) const unsigned d_sobolV[8 * 32] = {
     2147483648u, 1073741824u, 536870912u, 268435456u, 134217728u, 67108864u, 33554432u, 16777216u, 8388608u, 4194304u, 2097152u, 1048576u, 524288u, 262144u, 131072u, 65536u, 32768u, 16384u, 8192u, 4096u, 2048u, 1024u, 512u, 256u, 128u, 64u, 32u, 16u, 8u, 4u, 2u, 1u,
     2147483648u, 3221225472u, 2684354560u, 4026531840u, 2281701376u, 3422552064u, 2852126720u, 4278190080u, 2155872256u, 3233808384u, 2694840320u, 4042260480u, 2290614272u, 3435921408u, 2863267840u, 4294901760u, 2147516416u, 3221274624u, 2684395520u, 4026593280u, 2281736192u, 3422604288u, 2852170240u, 4278255360u, 2155905152u, 3233857728u, 2694881440u, 4042322160u, 2290649224u, 3435973836u, 2863311530u, 4294967295u,
     2147483648u, 3221225472u, 1610612736u, 2415919104u, 3892314112u, 1543503872u, 2382364672u, 3305111552u, 1753219072u, 2629828608u, 3999268864u, 1435500544u, 2154299392u, 3231449088u, 1626210304u, 2421489664u, 3900735488u, 1556135936u, 2388680704u, 3314585600u, 1751705600u, 2627492864u, 4008611328u, 1431684352u, 2147543168u, 3221249216u, 1610649184u, 2415969680u, 3892340840u, 1543543964u, 2382425838u, 3305133397u,
@@ -553,8 +553,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 const Mat mat = load_material(sc, surf_tri);
                 const unsigned frame = (unsigned)(P.frame_begin + fidx);
                 const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
-                const float su = sobol_dim(d_sobolV, bounce * 2, gray);
-                const float sv = sobol_dim(d_sobolV, bounce * 2 + 1, gray);
+                float su, sv;
+                sobol_vec2(d_sobolV, bounce, gray, &su, &sv);
                 const float xi_1 = cp_rotate(su, cpu);
                 const float xi_2 = cp_rotate(sv, cpv);
                 const float xi_3 = rand01(seed);
@@ -1085,6 +1085,8 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
     rc = fill_params(s, d, &P, &blocks, true);
     if (rc != RT_OK) return rc;
     P.max_bounce = d->max_bounce > 0 ? d->max_bounce : (d->mode == RT_MODE_CHAP5 ? 4 : 6);
+    if (d->mode == RT_MODE_CHAP5 && P.max_bounce > 4)  // sobolVec2(i, bounce) reads V[(2*bounce+1)*32 + j] of the 8-dimension table (f5:339, 883)
+        return set_error(RT_ERR_INVALID_ARG, "rt_render: mode 5 supports max_bounce <= 4 (the reference's Sobol table has 8 dimensions), got %d", P.max_bounce);
     P.accum = accum_dev;
     P.stats = stats_dev;
     P.queue = s->d_queue;
