@@ -483,26 +483,31 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (isA && miss) {
                 Lo = color, first_tri = -1, fin = true;
             }
-            if (MODE == RT_MODE_CHAP5 && h && kind == K_SHADOW && miss) {
-                const float mis_weight = misMixWeight(pdf_light, pdf_brdf);
-                Lo += mis_weight * history * color * f_r * dot(N, L) / pdf_light;  // f5:879-880
-            }
             const float cosine_i = fmax_(0.0f, dot(N, L));  // chapters 3/4
             const float pdf_uniform = 1.0f / (2.0f * PI_);
-            if (isD) {
-                if (MODE == RT_MODE_CHAP5) {
-                    if (!d_alive) {
-                        fin = true;
-                    } else if (miss) {
-                        const float NdotL = dot(N, L);
-                        const float mis_weight = misMixWeight(pdf_brdf, pdf_light);
-                        Lo += mis_weight * history * color * NdotL * f_r / pdf_brdf;  // f5:910-911
-                        fin = true;
+            if (MODE == RT_MODE_CHAP5) {
+                // f5:879-880 (env-visibility ray escaped), f5:910-911 (BRDF ray escaped), f5:915 + 920 (BRDF ray hit): three
+                // disjoint sets of lanes, one shared quotient.  Each lane's numerator is built in its own line's order.
+                const bool c_miss = h && kind == K_SHADOW && miss, d_miss = d_alive && miss, d_hit = d_alive && !miss;
+                if (isD && !d_alive) fin = true;  // f5:901
+                if (c_miss || d_miss || d_hit) {
+                    const float NdotL = dot(N, L);
+                    vec3 base;
+                    if (d_hit) {
+                        const float* T = sc.tris + (size_t)best_tri * 36 + 18;
+                        base = history * v3(T[0], T[1], T[2]);  // history * Le
+                    } else {
+                        const float mis_weight = misMixWeight(c_miss ? pdf_light : pdf_brdf, c_miss ? pdf_brdf : pdf_light);
+                        base = mis_weight * history * color;
                     }
-                } else if (miss) {
-                    Lo += history * color * f_r * cosine_i / pdf_uniform;  // f4:530, f3:401
-                    fin = true;
+                    const vec3 num = c_miss ? (base * f_r * NdotL) : (base * NdotL * f_r);
+                    Lo += num / (c_miss ? pdf_light : pdf_brdf);
+                    if (d_hit) history *= NdotL * f_r / pdf_brdf;  // f5:920
+                    if (d_miss) fin = true;
                 }
+            } else if (isD && miss) {
+                Lo += history * color * f_r * cosine_i / pdf_uniform;  // f4:530, f3:401
+                fin = true;
             }
             // step 4: the ray hit a surface: finish the hit record (smooth normal), move the path there
             if (STATS) { const int c_ = __popcll(__ballot((isA || d_alive) && !miss)); if (lane == 0) sg[2] += c_; }
@@ -511,11 +516,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 if (isD) {
                     const float* T = sc.tris + (size_t)best_tri * 36 + 18;
                     const vec3 Le = v3(T[0], T[1], T[2]);
-                    if (MODE == RT_MODE_CHAP5) {
-                        const float NdotL = dot(N, L);
-                        Lo += history * Le * NdotL * f_r / pdf_brdf;  // f5:915
-                        history *= NdotL * f_r / pdf_brdf;            // f5:920
-                    } else {
+                    if (MODE != RT_MODE_CHAP5) {  // (chapter 5: done with the escaped rays above)
                         if (MODE == RT_MODE_CHAP4)
                             Lo += history * Le * cosine_i / pdf_uniform;        // f4:535: no f_r
                         else
