@@ -244,3 +244,15 @@ def test_deep_tree_spills_stack_exactly():
     img = sc2.render(d4, 0, 2)
     ref, _ = O.render(tris, nodes, hdr, None, 32, 32, 4, eye, np.eye(4, dtype=np.float32).reshape(16), 0, 2)
     _assert_images_equal(img, ref, "deep tree render")
+
+
+def test_mode5_rejects_more_bounces_than_the_sobol_table_holds(scene_small, hdr_pair):
+    """f5:339 holds 8 Sobol dimensions = 4 bounces (f5:883, 949); a larger max_bounce would index past the table."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    d = rt.make_desc(16, 16, mode=5, max_bounce=5)
+    with pytest.raises(rt.RtError):
+        sc.render(d, 0, 1)
+    d = rt.make_desc(16, 16, mode=4, max_bounce=9)  # chapters 3/4 use rand() only: any depth
+    assert np.isfinite(sc.render(d, 0, 1)).all()
