@@ -128,7 +128,7 @@ class Mesh:
         _check(_lib.rt_mesh_create(C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.rt_mesh_destroy(self._h)
             self._h = None
 
@@ -253,7 +253,7 @@ class Scene:
                                     C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:  # (_lib is None while the interpreter shuts down)
             _lib.rt_scene_destroy(self._h)
             self._h = None
 
