@@ -90,6 +90,7 @@ struct RenderParams {
     unsigned long long* stats;  // 6 counters (STATS builds)
     int refill;            // lanes waiting for a handler that trigger a handler pass
     int leaf_lanes;        // lanes holding a leaf that trigger a cooperative leaf pass
+    int wait_budget;       // lane-passes spent waiting for the shade pass that trigger it
     int32_t* hit_tri;      // primary-hit query outputs
     float* hit_dist;
 };
@@ -330,6 +331,7 @@ __device__ __forceinline__ void flush_stats(const RenderParams& P, const Stats& 
 enum LaneOp { OP_INT = 0, OP_LEAF = 1, OP_H = 2, OP_DONE = 3 };
 enum RayKind { K_PRIMARY = 0, K_SHADOW = 1, K_BOUNCE = 2, K_NONE = 3 };
 
+constexpr int kWaitBudget = 4000;  // lane-passes; of the order of (VALU cost of a shade pass) / (one lane's share of a traversal pass)
 constexpr int kHandlerLanes = 48;  // run a handler once this many lanes wait for it (or nothing is traversing)
 
 // hitAABB (f5:225-238) with hardware min/max.  Equal to the ternary form whenever no operand is NaN (the results are
@@ -430,6 +432,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     bool queue_empty = false;
     bool need_new = true;           // every lane asks for its first sample in the prologue pass
     int pick = OP_H;                // the prologue runs the shade pass once with no lane in OP_H: only its tail
+    int waited = 0;                 // wave-uniform: lane-passes spent waiting for the shade pass since the last one
     for (;;) {
 #ifdef RT_OP_CYCLES
         const long long oc_t0 = clock64();
@@ -767,7 +770,11 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
         if ((nI | nL | nH) == 0) break;
         // traversal: internal steps until enough lanes hold a leaf to fill a cooperative leaf pass
         const int tb = (nL >= P.leaf_lanes || nI == 0) ? OP_LEAF : OP_INT, tn = nI + nL;
-        pick = (tn == 0 || nH >= P.refill) ? OP_H : tb;
+        // shade: when enough lanes wait for it, or when the lane-passes they have spent waiting are worth a shade pass
+        // (long traversals: few lanes arrive per pass, and parking them until `refill` have gathered idles half the wave)
+        waited += nH;
+        pick = (tn == 0 || nH >= P.refill || waited >= P.wait_budget) ? OP_H : tb;
+        if (pick == OP_H) waited = 0;
         if (STATS && lane == 0) dg[2 * pick]++, dg[2 * pick + 1] += (pick == OP_H) ? nH : ((pick == OP_INT) ? nI : nL);
         if (STATS) {  // lanes that have finished all their frames and idle until the wave ends
             const int nD = __popcll(__ballot(op == OP_DONE));
@@ -1049,6 +1056,8 @@ static int fill_params(rt_scene* s, const rt_render_desc* d, RenderParams* P, in
     *blocks = render ? s->cu_count * 32 : ((d->width + 15) / 16) * ((d->height + 15) / 16);
     P->leaf_lanes = kLeafLanes;
     if (const char* e = getenv("RT_AMD_LEAF")) P->leaf_lanes = atoi(e) > 0 ? atoi(e) : kLeafLanes;  // tuning knob
+    P->wait_budget = kWaitBudget;
+    if (const char* e = getenv("RT_AMD_WAIT")) P->wait_budget = atoi(e) > 0 ? atoi(e) : kWaitBudget;  // tuning knob
     P->refill = kHandlerLanes;
     if (const char* e = getenv("RT_AMD_REFILL")) P->refill = atoi(e) > 0 ? atoi(e) : kHandlerLanes;  // tuning knob
     if (s->max_stack > kLdsDepth) {  // deep tree: per-thread global spill beyond the LDS part of the stack
