@@ -83,7 +83,7 @@ struct RenderParams {
     float cam[16];
     float* accum;
     float* samples;        // radiance samples of this launch, [frame - frame_begin][pixel][3]
-    unsigned* queue;       // work queue: the next unit (tile, frame group) to hand to a wave
+    unsigned* queue;       // work queues, one per XCD's band of tiles (64 B apart): the next unit (tile, frame group) of the band
     int unit_frames;       // frames per unit
     int* spill;            // global stack spill, [depth - kLdsDepth][thread]
     long long spill_stride;
@@ -390,7 +390,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     const DevScene& sc = P.sc;
     const int lane = threadIdx.x;
     const int tilesx = (P.width + 7) >> 3, n_tiles = tilesx * ((P.height + 7) >> 3);
-    const int n_units = n_tiles * ((P.frame_count + P.unit_frames - 1) / P.unit_frames);
+    const int n_groups = (P.frame_count + P.unit_frames - 1) / P.unit_frames;  // frame groups; a unit = (tile, group)
+    const int xcd = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;   // HW_REG_XCC_ID: which of the 8 XCDs runs this wave
     const size_t n_pixels = (size_t)P.width * P.height;
     int* const stk_lds = &s_stack[lane];
     int* const stk_spill = SPILL ? (P.spill + ((long long)blockIdx.x * kWave + lane)) : nullptr;
@@ -430,6 +431,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     int unit_tx0 = 0, unit_ty0 = 0, unit_f0 = 0;  // wave-uniform: the unit being handed out
     int unit_items = 0, next_item = 0;            // its size and the first item not handed out yet
     bool queue_empty = false;
+    unsigned open_bands = 0xffu;                  // wave-uniform: tile bands (one per XCD) that may still have units
     bool need_new = true;           // every lane asks for its first sample in the prologue pass
     int pick = OP_H;                // the prologue runs the shade pass once with no lane in OP_H: only its tail
     int waited = 0;                 // wave-uniform: lane-passes spent waiting for the shade pass since the last one
@@ -591,14 +593,27 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 if (asking == 0ull) break;  // wave-uniform
                 if (next_item >= unit_items) {
                     if (queue_empty) break;
-                    unsigned u = 0;
-                    if (lane == 0) u = __hip_atomic_fetch_add(P.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    u = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
-                    if (u >= (unsigned)n_units) {
+                    // take a unit: from this XCD's band of tiles first (neighbouring tiles walk the same nodes, and each
+                    // XCD has its own L2), then from the next band that still has work
+                    int tile = 0, group = 0;
+                    bool have = false;
+                    while (open_bands != 0u) {
+                        const int q = (xcd + __builtin_ctz(((open_bands >> xcd) | (open_bands << (8 - xcd))) & 0xffu)) & 7;
+                        const int band_begin = (int)((long long)n_tiles * q / 8), band_tiles = (int)((long long)n_tiles * (q + 1) / 8) - band_begin;
+                        unsigned u = 0;
+                        if (lane == 0) u = __hip_atomic_fetch_add(P.queue + q * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        u = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
+                        if (u < (unsigned)band_tiles * (unsigned)n_groups) {
+                            tile = band_begin + (int)(u % (unsigned)band_tiles), group = (int)(u / (unsigned)band_tiles);
+                            have = true;
+                            break;
+                        }
+                        open_bands &= ~(1u << q);  // that band is handed out completely
+                    }
+                    if (!have) {
                         queue_empty = true;
                         break;
                     }
-                    const int tile = (int)u % n_tiles, group = (int)u / n_tiles;  // all tiles of a frame group, then the next group
                     unit_tx0 = (tile % tilesx) * 8, unit_ty0 = (tile / tilesx) * 8, unit_f0 = group * P.unit_frames;
                     const int nf = P.frame_count - unit_f0 < P.unit_frames ? P.frame_count - unit_f0 : P.unit_frames;
                     unit_items = nf * kWave, next_item = 0;
@@ -995,7 +1010,7 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     } while (0)
     HIPCHK_S(hipSetDevice(s->device));
     HIPCHK_S(hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, s->device));
-    HIPCHK_S(hipMalloc((void**)&s->d_queue, 256));
+    HIPCHK_S(hipMalloc((void**)&s->d_queue, 8 * 16 * sizeof(unsigned)));
     if (nT > 0) {
         HIPCHK_S(hipMalloc(&s->d_ttri, ttri.size() * 4));
         HIPCHK_S(hipMemcpy(s->d_ttri, ttri.data(), ttri.size() * 4, hipMemcpyHostToDevice));
@@ -1124,7 +1139,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         P.frame_count = frame_count - done < launch_frames ? frame_count - done : launch_frames;
         const long long n_units = (long long)n_tiles * ((P.frame_count + P.unit_frames - 1) / P.unit_frames);
         const int grid = (int)(n_units < blocks ? n_units : blocks);  // persistent waves: at most what the device holds
-        HIPCHK(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned), stream));
+        HIPCHK(hipMemsetAsync(s->d_queue, 0, 8 * 16 * sizeof(unsigned), stream));
         TimedLaunch tl;
         HIPCHK(hipEventCreate(&tl.a));
         HIPCHK(hipEventCreate(&tl.b));
