@@ -403,3 +403,11 @@ def test_scene_cache_round_trip_and_rejections(tmp_path):
     rt.scene_cache_save(path, 5, np.zeros((0, 36), np.float32), np.zeros((1, 12), np.float32))
     t0, n0 = rt.scene_cache_load(path, 5)
     assert t0.shape == (0, 36) and n0.shape == (1, 12)
+
+
+def test_cli_driver_chapter1_writes_a_png(tmp_path):
+    from ray_tracing_amd import render
+    out = tmp_path / "c1.png"
+    assert render.main(["--config", "1", "--width", "24", "--height", "16", "--frames", "2", "--out", str(out)]) == 0
+    raw = out.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n" and raw[16:24] == (24).to_bytes(4, "big") + (16).to_bytes(4, "big")
