@@ -5,6 +5,10 @@
 // proxies with the same comparator on the same ranges in the same sequence and gathers the triangles once at the end.
 // Everything else (fp32 operation order, the INF = 114514 clamps, `float split`, strict `<` tie rules, pre-order node
 // numbering, left subtree built before right) follows the reference line by line.  Compile with -ffp-contract=off.
+//
+// Sibling subtrees work on disjoint ranges, so they are built as OpenMP tasks into a pointer tree, which is then numbered
+// in the reference's order (a node before its left subtree, the whole left subtree before the right one).  Inside a node the
+// four sorts stay sequential: each starts from the order the previous one left, as in the reference.
 #include <stdlib.h>
 #include <string.h>
 
@@ -32,24 +36,44 @@ struct BNode {
     int n, index;
 };
 
+struct TNode {  // node of the tree as it is built; numbered afterwards
+    vec3 AA, BB;
+    int n, index;
+    TNode *left, *right;
+};
+constexpr int kTaskMin = 8192;  // ranges at least this long build their two subtrees as parallel tasks
+
 struct Builder {
     std::vector<Proxy> px;
     std::vector<vec3> tmin, tmax;  // per original triangle: min/max over p1,p2,p3 as min(p1, min(p2, p3))
     std::vector<BNode> nodes;
     int leaf_n;
 
-    int new_node(int l, int r) {
-        nodes.push_back(BNode());
-        const int id = (int)nodes.size() - 1;
-        BNode& nd = nodes[id];
-        nd.left = nd.right = nd.n = nd.index = 0;
-        nd.AA = v3(1145141919, 1145141919, 1145141919);
-        nd.BB = v3(-1145141919, -1145141919, -1145141919);
+    TNode* new_node(int l, int r) {
+        TNode* nd = new TNode();
+        nd->left = nd->right = nullptr;
+        nd->n = nd->index = 0;
+        nd->AA = v3(1145141919, 1145141919, 1145141919);
+        nd->BB = v3(-1145141919, -1145141919, -1145141919);
         for (int i = l; i <= r; i++) {
             const vec3 mn = tmin[px[i].idx], mx = tmax[px[i].idx];
-            nd.AA.x = fmin_(nd.AA.x, mn.x), nd.AA.y = fmin_(nd.AA.y, mn.y), nd.AA.z = fmin_(nd.AA.z, mn.z);
-            nd.BB.x = fmax_(nd.BB.x, mx.x), nd.BB.y = fmax_(nd.BB.y, mx.y), nd.BB.z = fmax_(nd.BB.z, mx.z);
+            nd->AA.x = fmin_(nd->AA.x, mn.x), nd->AA.y = fmin_(nd->AA.y, mn.y), nd->AA.z = fmin_(nd->AA.z, mn.z);
+            nd->BB.x = fmax_(nd->BB.x, mx.x), nd->BB.y = fmax_(nd->BB.y, mx.y), nd->BB.z = fmax_(nd->BB.z, mx.z);
         }
+        return nd;
+    }
+
+    // pre-order numbering, c5:466-467 / 587-590: vector index = creation order; frees the tree
+    int number(TNode* t) {
+        if (!t) return 0;
+        const int id = (int)nodes.size();
+        nodes.push_back(BNode());
+        nodes[id].AA = t->AA, nodes[id].BB = t->BB, nodes[id].n = t->n, nodes[id].index = t->index;
+        const int left = number(t->left);
+        nodes[id].left = left;
+        const int right = number(t->right);
+        nodes[id].right = right;
+        delete t;
         return id;
     }
 
@@ -61,13 +85,13 @@ struct Builder {
         if (axis == 2) std::sort(b, e, cmpz);
     }
 
-    int build_sah(int l, int r) {
-        if (l > r) return 0;
-        const int id = new_node(l, r);
+    TNode* build_sah(int l, int r) {
+        if (l > r) return nullptr;
+        TNode* const nd = new_node(l, r);
         if ((r - l + 1) <= leaf_n) {
-            nodes[id].n = r - l + 1;
-            nodes[id].index = l;
-            return id;
+            nd->n = r - l + 1;
+            nd->index = l;
+            return nd;
         }
         float Cost = kINF;
         int Axis = 0;
@@ -119,33 +143,45 @@ struct Builder {
         sort_axis(Axis, l, r);
         { std::vector<vec3>().swap(leftMax); std::vector<vec3>().swap(leftMin); }
         { std::vector<vec3>().swap(rightMax); std::vector<vec3>().swap(rightMin); }
-        const int left = build_sah(l, Split);
-        nodes[id].left = left;
-        const int right = build_sah(Split + 1, r);
-        nodes[id].right = right;
-        return id;
+        if (cnt >= kTaskMin) {
+#pragma omp task default(shared)
+            nd->left = build_sah(l, Split);
+#pragma omp task default(shared)
+            nd->right = build_sah(Split + 1, r);
+#pragma omp taskwait
+        } else {
+            nd->left = build_sah(l, Split);
+            nd->right = build_sah(Split + 1, r);
+        }
+        return nd;
     }
 
-    int build_median(int l, int r) {
-        if (l > r) return 0;
-        const int id = new_node(l, r);
+    TNode* build_median(int l, int r) {
+        if (l > r) return nullptr;
+        TNode* const nd = new_node(l, r);
         if ((r - l + 1) <= leaf_n) {
-            nodes[id].n = r - l + 1;
-            nodes[id].index = l;
-            return id;
+            nd->n = r - l + 1;
+            nd->index = l;
+            return nd;
         }
-        const float lenx = nodes[id].BB.x - nodes[id].AA.x;
-        const float leny = nodes[id].BB.y - nodes[id].AA.y;
-        const float lenz = nodes[id].BB.z - nodes[id].AA.z;
+        const float lenx = nd->BB.x - nd->AA.x;
+        const float leny = nd->BB.y - nd->AA.y;
+        const float lenz = nd->BB.z - nd->AA.z;
         if (lenx >= leny && lenx >= lenz) sort_axis(0, l, r);
         if (leny >= lenx && leny >= lenz) sort_axis(1, l, r);
         if (lenz >= lenx && lenz >= leny) sort_axis(2, l, r);
         const int mid = (l + r) / 2;
-        const int left = build_median(l, mid);
-        const int right = build_median(mid + 1, r);
-        nodes[id].left = left;
-        nodes[id].right = right;
-        return id;
+        if (r - l + 1 >= kTaskMin) {
+#pragma omp task default(shared)
+            nd->left = build_median(l, mid);
+#pragma omp task default(shared)
+            nd->right = build_median(mid + 1, r);
+#pragma omp taskwait
+        } else {
+            nd->left = build_median(l, mid);
+            nd->right = build_median(mid + 1, r);
+        }
+        return nd;
     }
 };
 
@@ -176,10 +212,11 @@ extern "C" int rt_bvh_build(rt_mesh* mesh, int leaf_n, int use_sah, float** node
     // dummy node 0 (c5:835-841); its fields are never read by a valid traversal.
     b.nodes.push_back(BNode());
     memset((void*)&b.nodes[0], 0, sizeof(BNode));
-    if (use_sah)
-        b.build_sah(0, nT - 1);
-    else
-        b.build_median(0, nT - 1);
+    TNode* root = nullptr;
+#pragma omp parallel
+#pragma omp single
+    root = use_sah ? b.build_sah(0, nT - 1) : b.build_median(0, nT - 1);
+    b.number(root);
 
     std::vector<TriRec> permuted((size_t)nT);
     for (int i = 0; i < nT; ++i) permuted[i] = mesh->tris[b.px[i].idx];
