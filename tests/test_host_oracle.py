@@ -411,3 +411,19 @@ def test_cli_driver_chapter1_writes_a_png(tmp_path):
     assert render.main(["--config", "1", "--width", "24", "--height", "16", "--frames", "2", "--out", str(out)]) == 0
     raw = out.read_bytes()
     assert raw[:8] == b"\x89PNG\r\n\x1a\n" and raw[16:24] == (24).to_bytes(4, "big") + (16).to_bytes(4, "big")
+
+
+def test_bvh_build_is_identical_for_any_thread_count():
+    """Sibling subtrees are built as OpenMP tasks; triangles permutation and node numbering must not depend on that."""
+    import hashlib
+    import subprocess
+    import sys
+    code = ("import hashlib\nfrom ray_tracing_amd import scenes\nt, n = scenes.chap5_scene()\n"
+            "print(hashlib.sha256(t.tobytes() + n.tobytes()).hexdigest())\n")
+    out = []
+    for th in ("1", "3", "8"):
+        env = dict(os.environ, OMP_NUM_THREADS=th, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        out.append(r.stdout.strip())
+    assert out[0] == out[1] == out[2] and len(out[0]) == 64
