@@ -427,3 +427,17 @@ def test_bvh_build_is_identical_for_any_thread_count():
         assert r.returncode == 0, r.stderr
         out.append(r.stdout.strip())
     assert out[0] == out[1] == out[2] and len(out[0]) == 64
+
+
+def test_host_layer_is_clean_under_asan_and_ubsan(tmp_path):
+    """tests/host_sanitize.cpp walks the CPU entry points of the C ABI (malformed inputs included) in a build with
+    -fsanitize=address,undefined; any finding aborts it."""
+    import subprocess
+    csrc = os.path.join(ROOT, "ray_tracing_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "sanitize"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)  # ASan must come first in the library list
+    r = subprocess.run([os.path.join(csrc, "host_sanitize"), os.path.join(ROOT, "assets"), str(tmp_path)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "host_sanitize: ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
