@@ -1,9 +1,10 @@
 // Device layer: scene upload/validation/repacking and the HIP kernels of the per-pixel path loop (gfx950).
 //
-// Replaces pass1.draw() of the reference (c5:755 -> fshader.fsh main()).  One lane owns one pixel and walks
-// frameCounter = frame_begin .. frame_begin+frame_count-1 in order, so the fp32 running mean of f5:954-955 is
-// reproduced exactly.  BVH traversal visits nodes in the reference's order without culling (f5:259-311), on a
-// device-private repack of the reference arrays:
+// Replaces pass1.draw() of the reference (c5:755 -> fshader.fsh main()).  Every (pixel, frameCounter) sample of
+// frame_begin .. frame_begin+frame_count-1 is an independent work item traced by whichever lane is free; the samples of a
+// pixel are then folded in frame order (fold_kernel), so the fp32 running mean of f5:954-955 is reproduced exactly.
+// BVH traversal visits nodes in the reference's order without culling (f5:259-311), on a device-private repack of the
+// reference arrays:
 //   * node record (64 B): both children's boxes + packed child entries -> one record per internal visit instead of the
 //     reference's 3 x 48 B node fetches;
 //   * traversal triangle (48 B): p1 p2 p3 + the plane normal normalize(cross(p2-p1,p3-p1)) precomputed with the
@@ -30,7 +31,7 @@ namespace rta {
                                                __FILE__, __LINE__);                                        \
     } while (0)
 
-constexpr int kBlock = 256;      // 16x16 pixels; each wave64 owns an 8x8 sub-tile
+constexpr int kBlock = 256;      // primary_kernel: 16x16 pixels; each wave64 owns an 8x8 sub-tile
 #ifndef RT_LDS_DEPTH
 #define RT_LDS_DEPTH 18
 #endif
@@ -317,7 +318,7 @@ __device__ __forceinline__ void flush_stats(const RenderParams& P, const Stats& 
 
 // ---- the path loop as a per-lane state machine with a wave-level scheduler ------------------------------------
 // fshader.fsh main() (f5:926-988) + pathTracingImportanceSampling (f5:850-923) / pathTracing (f4:505-541, f3:378-416),
-// cut at every hitBVH call.  A lane owns one pixel and walks its frames in order.  At any moment a lane waits for exactly
+// cut at every hitBVH call.  A lane works on one sample (pixel, frame) at a time.  At any moment it waits for exactly
 // one "op":
 //   OP_INT   one internal-node step of hitBVH (two child boxes, f5:282-307)
 //   OP_LEAF  the triangles of the leaf it holds (hitArray, f5:243-256), served by the cooperative leaf pass
@@ -349,7 +350,7 @@ __device__ __forceinline__ bool finite3(vec3 v) {
     return (fabs_(v.x) < inf) && (fabs_(v.y) < inf) && (fabs_(v.z) < inf);
 }
 
-constexpr int kWave = 64;         // render_kernel: one wave64 per workgroup, an 8x8 pixel tile
+constexpr int kWave = 64;         // render_kernel: one wave64 per workgroup; work units are 8x8 pixel tiles x kUnitFrames frames
 constexpr int kLaunchFrames = 32;  // frames per kernel launch (sample buffer = W x H x frames x 12 B)
 constexpr int kUnitFrames = 2;     // frames per work unit (one 8x8 tile x this many frames = 128 samples)
 constexpr size_t kMaxSampleBytes = (size_t)4 << 30;
