@@ -256,3 +256,48 @@ def test_mode5_rejects_more_bounces_than_the_sobol_table_holds(scene_small, hdr_
         sc.render(d, 0, 1)
     d = rt.make_desc(16, 16, mode=4, max_bounce=9)  # chapters 3/4 use rand() only: any depth
     assert np.isfinite(sc.render(d, 0, 1)).all()
+
+
+def test_config5_full_resolution_bit_exact(scene_chap5, hdr_pair):
+    """BASELINE config 5 at its full image size (1920x1080, bench camera), 6 frames: every pixel equals the oracle's."""
+    tris, nodes = scene_chap5
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(0.0, 20.0, 4.0)
+    W, H, F = 1920, 1080, 6
+    d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+    img = sc.render(d, 0, F)
+    ref, ost = O.render(tris, nodes, hdr, cache, W, H, 5, eye, cam, 0, F)
+    _assert_images_equal(img, ref, "config 5 at 1080p")
+    assert sc.render_stats(d, 0, F) == ost
+
+
+def test_config5_full_frame_count_properties(scene_chap5, hdr_pair):
+    """BASELINE config 5 at its full size (1080p, frames 0..1023), through size-independent properties: the running mean
+    of one 1024-frame call equals the same frames in two calls cut at an odd frame (bit-exact), and agrees with the
+    sum-mode buffer / 1024 and with a 32-frame render statistically."""
+    tris, nodes = scene_chap5
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(0.0, 20.0, 4.0)
+    W, H, F = 1920, 1080, 1024
+    d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+    one = sc.render(d, 0, F)
+    two = sc.render(d, 0, 437)
+    two = sc.render(d, 437, F - 437, two)
+    _assert_images_equal(one, two, "1024 frames, one call vs two")
+    ds = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam, accumulate=rt.RT_ACCUM_SUM)
+    s = sc.render(ds, 0, F)
+    ok = np.isfinite(one) & np.isfinite(s)
+    assert ok.mean() > 0.999
+    assert np.allclose(s[ok] / F, one[ok], rtol=5e-4, atol=1e-5)  # same samples, different fp32 summation order
+    few = sc.render(d, 0, 32)
+    a = rt.tonemap_rgb8(one).astype(np.float64) / 255.0
+    b = rt.tonemap_rgb8(few).astype(np.float64) / 255.0
+    # 32 spp is a noisier estimate of the same image: tone-mapped RMSE <= 0.05 per pixel, <= 0.01 after an 8x8 box filter,
+    # mean radiance within 1 %
+    assert np.sqrt(np.mean((a - b) ** 2)) <= 0.05
+    A, B = (x.reshape(H // 8, 8, W // 8, 8, 3).mean((1, 3)) for x in (a, b))
+    assert np.sqrt(np.mean((A - B) ** 2)) <= 0.01
+    fin = np.isfinite(one) & np.isfinite(few)
+    assert abs(one[fin].mean() - few[fin].mean()) <= 0.01 * one[fin].mean()
