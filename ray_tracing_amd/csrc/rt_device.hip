@@ -869,6 +869,15 @@ struct TimedLaunch {
     hipEvent_t a, b;
 };
 static thread_local std::vector<TimedLaunch> g_launches;
+constexpr size_t kMaxTimedLaunches = 1024;  // bound on the events kept for rt_kernel_time_ms
+static void remember_launch(const TimedLaunch& tl) {
+    if (g_launches.size() >= kMaxTimedLaunches) {  // nobody is reading the timings: keep the most recent half
+        for (size_t k = 0; k < kMaxTimedLaunches / 2; ++k)
+            (void)hipEventDestroy(g_launches[k].a), (void)hipEventDestroy(g_launches[k].b);
+        g_launches.erase(g_launches.begin(), g_launches.begin() + kMaxTimedLaunches / 2);
+    }
+    g_launches.push_back(tl);
+}
 static thread_local int g_device = -1;
 
 }  // namespace rta
@@ -1161,9 +1170,9 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
 #undef LAUNCH
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(tl.b, stream));
-        if (!STATS)
-            g_launches.push_back(tl);
-        else {
+        if (!STATS) {
+            remember_launch(tl);
+        } else {
             (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
         }
         hipLaunchKernelGGL(fold_kernel, dim3(fold_blocks), dim3(256), 0, stream, P);
@@ -1258,7 +1267,7 @@ int rt_primary_hits_device(rt_scene* s, const rt_render_desc* d, int32_t* tri_de
         hipLaunchKernelGGL((primary_kernel<false, false>), dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, P);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(tl.b, (hipStream_t)stream));
-    g_launches.push_back(tl);
+    remember_launch(tl);
     return RT_OK;
 }
 

@@ -332,3 +332,19 @@ def test_synthetic_scene_small_instance_bit_exact(hdr_pair):
     _assert_images_equal(img, ref, "synthetic scene")
     assert sc.render_stats(d, 0, F) == ost
     assert ost["internal_nodes"] / ost["rays"] > 20  # long traversals: the waiting-budget rule of the scheduler is exercised
+
+
+def test_many_small_launches_keep_a_bounded_timing_list(scene_small, hdr_pair):
+    """An interactive caller renders one frame per call and never reads rt_kernel_time_ms: the event list stays bounded."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    d = rt.make_desc(8, 8, mode=5)
+    rt.kernel_time_ms(reset=True)
+    img = None
+    for f in range(1300):
+        img = sc.render(d, f, 1, img)
+    ms, n = rt.kernel_time_ms(reset=True)
+    assert 512 <= n <= 1024 and ms > 0
+    ref, _ = O.render(tris, nodes, hdr, cache, 8, 8, 5, d.eye, d.camera_rotate, 0, 1300)
+    _assert_images_equal(img, ref, "1300 one-frame calls")
