@@ -165,7 +165,7 @@ def main():
                 "note": f"scene arrays {(tris.nbytes + nodes.nbytes) / 1e6:.1f} MB; the path loop is VALU-issue-bound, HBM is not the binding resource: see DESIGN.md section 5",
             }
             result["mrays_per_s_per_gpu"] = result["value"] * rays_per_path / world
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed on rank 0 at N = 1 only
             import oracle_lib as O
             cw, ch, cs = (int(x) for x in args.cpu_sample.split("x"))
             cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
