@@ -20,6 +20,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def _pmc_entry(key):
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as f:
+            return json.load(f).get(key, {})
+    except (OSError, ValueError):
+        return {}
+
+
 def _pmc_traffic(key):
     """HBM bytes per launch of the path-loop kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, in
     bytes; collected by tools/profile_round.sh, stored by hand in profiles/hbm_traffic.json).  None when this workload
@@ -29,6 +37,18 @@ def _pmc_traffic(key):
             return json.load(f).get(key, {}).get("bytes_per_launch")
     except (OSError, ValueError):
         return None
+
+
+def _valu_block(flops_per_launch, kern_ms, wave_insts):
+    """The roofline that does bind this kernel: fp32 VALU issue.  `issue_frac` = VALU wave-instructions of one launch (PMC
+    SQ_INSTS_VALU, committed profile) x the measured issue ceiling of dependent fp32 VALU code at this occupancy (2.6 cycles
+    per wave-instruction per SIMD, tools/ubench/valu_rate.hip) / (kernel time x 2.4 GHz x 1024 SIMDs)."""
+    out = {"achieved_tflops": flops_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0, "peak_tflops_no_fma": 78.6}
+    if wave_insts and kern_ms > 0:
+        simd_cycles = kern_ms * 1e-3 * 2.4e9 * 1024.0
+        out.update({"wave_instructions_per_launch": wave_insts, "issue_cycles_per_instruction": simd_cycles / wave_insts,
+                    "issue_ceiling_cycles_per_instruction": 2.6, "issue_frac": wave_insts * 2.6 / simd_cycles})
+    return out
 
 
 def main():
@@ -160,8 +180,8 @@ def main():
                 "kernel": f"render_kernel<chap{args.mode}>", "kernel_ms": kern_ms, "launches": launches,
                 "bytes_per_ray": bytes_per_ray, "rays_per_path": rays_per_path,
                 "per_ray": {"I": I, "Lf": Lf, "T": T, "H": Hh},
-                "valu": {"achieved_tflops": flops_per_ray * rays_per_path * paths_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
-                         "peak_tflops_no_fma": 78.6},
+                "valu": _valu_block(flops_per_ray * rays_per_path * paths_per_launch, kern_ms,
+                                    _pmc_entry(f"{args.scene}_chap{args.mode}_{W}x{H}_spp{spp}").get("valu_wave_instructions_per_launch")),
                 "note": f"scene arrays {(tris.nbytes + nodes.nbytes) / 1e6:.1f} MB; the path loop is VALU-issue-bound, HBM is not the binding resource: see DESIGN.md section 5",
             }
             result["mrays_per_s_per_gpu"] = result["value"] * rays_per_path / world
