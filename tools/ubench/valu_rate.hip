@@ -4,6 +4,19 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+__global__ void __launch_bounds__(64) kpk(float* out, long long* cyc, int iters, float a, float b) {
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    v2 x0 = {(float)threadIdx.x, 1.f}, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f, x4 = x0 + 4.f, x5 = x0 + 5.f, x6 = x0 + 6.f, x7 = x0 + 7.f;
+    const v2 m = {a, a};
+    for (int i = 0; i < iters; ++i) {
+        asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
+                     "v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(m));
+    }
+    const v2 r = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    out[blockIdx.x * 64 + threadIdx.x] = r.x + r.y;
+}
+
 template <int KIND>
 __global__ void __launch_bounds__(64) k(float* out, long long* cyc, int iters, float a, float b) {
     const long long c0 = clock64();
@@ -29,9 +42,9 @@ static void run(const char* name, float* d, long long* cyc, int wps) {
     const int iters = 200000, blocks = 256 * 4 * wps;
     hipEvent_t a, b;
     (void)hipEventCreate(&a), (void)hipEventCreate(&b);
-    k<KIND><<<blocks, 64>>>(d, cyc, 100, 1.0001f, 0.5f);
+    if (KIND == 3) kpk<<<blocks, 64>>>(d, cyc, 100, 1.0001f, 0.5f); else k<KIND><<<blocks, 64>>>(d, cyc, 100, 1.0001f, 0.5f);
     (void)hipEventRecord(a);
-    k<KIND><<<blocks, 64>>>(d, cyc, iters, 1.0001f, 0.5f);
+    if (KIND == 3) kpk<<<blocks, 64>>>(d, cyc, iters, 1.0001f, 0.5f); else k<KIND><<<blocks, 64>>>(d, cyc, iters, 1.0001f, 0.5f);
     (void)hipEventRecord(b);
     (void)hipEventSynchronize(b);
     float ms;
@@ -52,6 +65,7 @@ int main() {
     for (int w : {1, 2, 4, 8}) run<0>("fma", d, cyc, w);
     for (int w : {1, 2, 4, 8}) run<1>("mul", d, cyc, w);
     for (int w : {1, 2, 4, 8}) run<2>("minmax", d, cyc, w);
+    for (int w : {1, 2, 4, 5, 8}) run<3>("pk_mul (2 fp32 per lane)", d, cyc, w);
     (void)hipFree(d);
     return 0;
 }
