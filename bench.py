@@ -82,7 +82,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1: run the multi-GPU code path (sum buffers + reduce) with a single rank, to rehearse it on a 1-GPU box
+    multi = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
 
@@ -103,7 +105,7 @@ def main():
     # floor slab (y = 0.2) and sees only its underside, so the first thing a user does is drag the view up
     eye, cam = rt.camera(0.0, args.up_angle, 4.0)
     W, H, spp = args.width, args.height, args.spp
-    acc_mode = rt.RT_ACCUM_SUM if world > 1 else rt.RT_ACCUM_RUNNING_MEAN
+    acc_mode = rt.RT_ACCUM_SUM if multi else rt.RT_ACCUM_RUNNING_MEAN
     desc = rt.make_desc(W, H, mode=args.mode, eye=eye, camera_rotate=cam, accumulate=acc_mode)
 
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
@@ -112,15 +114,15 @@ def main():
     def step(i):
         # rank r of `world` owns frames [ (i*world + r)*spp, +spp ): disjoint frameCounter ranges (seed f5:320-323)
         fb, fc = parallel.frame_range(i, rank, world, spp)
-        if world > 1:
+        if multi:
             accum.zero_()
         scene.render_device(desc, fb, fc, accum.data_ptr(), stream)
-        if world > 1:
+        if multi:
             parallel.reduce_sum(accum, dist, dst=0)  # one RCCL reduce per step over xGMI
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -134,7 +136,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = rt.kernel_time_ms(reset=True)
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -195,7 +197,7 @@ def main():
             result["cpu_baseline"] = {"value": cw * ch * cs / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
                                       "sample": f"same scene/camera/mode at {cw}x{ch}, {cs} spp (oracle, OpenMP over rows), {dt:.1f} s"}
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -20,7 +20,7 @@ def frames_covered(steps: int, world: int, spp: int) -> int:
 
 def reduce_sum(accum, dist=None, dst: int = 0):
     """One sum-reduce of the per-rank accumulation buffers to `dst` (RCCL over xGMI on GPUs, gloo in CPU tests)."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():  # (a single rank reduces onto itself: used to rehearse the path)
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum
 
