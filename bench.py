@@ -108,17 +108,31 @@ def main():
     acc_mode = rt.RT_ACCUM_SUM if multi else rt.RT_ACCUM_RUNNING_MEAN
     desc = rt.make_desc(W, H, mode=args.mode, eye=eye, camera_rotate=cam, accumulate=acc_mode)
 
-    accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    # N = 1: one accumulation buffer (the running mean).  N > 1: two sum buffers, so that the RCCL reduce of step s (on its
+    # own stream) overlaps the path loop of step s + 1 on the other buffer.
+    bufs = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2 if multi else 1)]
+    main_stream = torch.cuda.current_stream(dev)
+    stream = main_stream.cuda_stream
+    comm_stream = torch.cuda.Stream(dev) if multi else None
+    reduced = [None, None]  # per buffer: event recorded when its last reduce finished
 
     def step(i):
         # rank r of `world` owns frames [ (i*world + r)*spp, +spp ): disjoint frameCounter ranges (seed f5:320-323)
         fb, fc = parallel.frame_range(i, rank, world, spp)
+        accum = bufs[i % len(bufs)]
         if multi:
+            if reduced[i % 2] is not None:
+                main_stream.wait_event(reduced[i % 2])  # the reduce that last read this buffer
             accum.zero_()
         scene.render_device(desc, fb, fc, accum.data_ptr(), stream)
         if multi:
-            parallel.reduce_sum(accum, dist, dst=0)  # one RCCL reduce per step over xGMI
+            rendered = torch.cuda.Event()
+            rendered.record(main_stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(rendered)
+                parallel.reduce_sum(accum, dist, dst=0)  # one RCCL reduce per step over xGMI
+                reduced[i % 2] = torch.cuda.Event()
+                reduced[i % 2].record(comm_stream)
 
     def fence():
         torch.cuda.synchronize(dev)
