@@ -348,3 +348,28 @@ def test_many_small_launches_keep_a_bounded_timing_list(scene_small, hdr_pair):
     assert 512 <= n <= 1024 and ms > 0
     ref, _ = O.render(tris, nodes, hdr, cache, 8, 8, 5, d.eye, d.camera_rotate, 0, 1300)
     _assert_images_equal(img, ref, "1300 one-frame calls")
+
+
+def test_spp_split_over_two_virtual_ranks_on_one_gpu(scene_small, hdr_pair):
+    """the N-GPU spp split (disjoint frameCounter ranges into private sum buffers, one reduce, divide) equals the
+    1-GPU running mean up to fp32 summation order — here with both 'ranks' on one GPU."""
+    from ray_tracing_amd import parallel
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(5.0, 18.0, 3.4)
+    W, H, spp, world, steps = 96, 64, 5, 2, 3
+    ds = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam, accumulate=rt.RT_ACCUM_SUM)
+    total = np.zeros((H, W, 3), np.float64)
+    seen = []
+    for s in range(steps):
+        for r in range(world):
+            fb, fc = parallel.frame_range(s, r, world, spp)
+            seen += list(range(fb, fb + fc))
+            total += sc.render(ds, fb, fc)  # private sum buffer of (step, rank); the reduce is this +=
+    assert sorted(seen) == list(range(parallel.frames_covered(steps, world, spp)))
+    mean = parallel.normalize(total, len(seen))
+    dm = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+    one = sc.render(dm, 0, len(seen))
+    ok = np.isfinite(one) & np.isfinite(mean)
+    assert ok.mean() > 0.99 and np.allclose(mean[ok], one[ok], rtol=2e-4, atol=1e-5)
