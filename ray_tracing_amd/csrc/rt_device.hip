@@ -671,8 +671,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             // ---- one internal node (f5:282-307) ------------------------------------------------------------------
             if (op == OP_INT) {
                 if (STATS) st.internal++;
-                const float4 q0 = sc.nodes[cur * 4 + 0], q1 = sc.nodes[cur * 4 + 1], q2 = sc.nodes[cur * 4 + 2],
-                             q3 = sc.nodes[cur * 4 + 3];
+                const float4 q0 = sc.nodes[cur * 4 + 0], q1 = sc.nodes[cur * 4 + 1], q2 = sc.nodes[cur * 4 + 2];
+                const float2 q3 = *reinterpret_cast<const float2*>(&sc.nodes[cur * 4 + 3]);  // the two child entries
                 const vec3 lAA = v3(q0.x, q0.y, q0.z), lBB = v3(q0.w, q1.x, q1.y);
                 const vec3 rAA = v3(q1.z, q1.w, q2.x), rBB = v3(q2.y, q2.z, q2.w);
                 float d1 = hitAABB_fast(S, invdir, lAA, lBB);
