@@ -724,7 +724,10 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             const int total = __shfl(incl, 63, 64);
             const int n_items = total < 64 ? total : 64;
             if (leaf) s_key[lane] = ~0ull;
-            for (int j = 0; __any(j < serve); ++j)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)  // the reference builds leaves of up to 8 triangles (c5:843): no loop overhead for those
+                if (j < serve) s_item[start + j] = ((ti + j) << 6) | lane;
+            for (int j = 8; __any(j < serve); ++j)
                 if (j < serve) s_item[start + j] = ((ti + j) << 6) | lane;
             __syncthreads();  // one wave per workgroup: a fence only
             if (lane < n_items) {
