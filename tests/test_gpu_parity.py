@@ -432,3 +432,49 @@ def test_axis_aligned_and_non_finite_rays(scene_small, hdr_pair):
         img = sc.render(dd, 0, 2)
         ref, _ = O.render(tris, nodes, hdr, cache, 24, 16, 5, e, ident, 0, 2)
         _assert_images_equal(img, ref, f"eye {eye}")
+
+
+def _random_soup(seed):
+    rng = np.random.RandomState(1000 + seed)
+    n = int(rng.randint(150, 1500))
+    c = rng.uniform(-1.5, 1.5, (n, 1, 3))
+    p = c + rng.normal(0, 0.25 * rng.rand(n, 1, 1) + 0.02, (n, 3, 3))
+    nrm = rng.normal(0, 1, (n, 3, 3))
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    t = np.zeros((n, 36), np.float32)
+    t[:, 0:9] = p.reshape(n, 9)
+    t[:, 9:18] = nrm.reshape(n, 9)
+    t[:, 18:21] = np.where(rng.rand(n, 1) < 0.05, rng.uniform(0, 8, (n, 3)), 0.0)   # a few emitters
+    t[:, 21:24] = rng.rand(n, 3)                                                      # baseColor
+    t[:, 24:34] = rng.rand(n, 10)                                                     # subsurface .. clearcoatGloss
+    ext = rng.randint(0, n, 40)                                                       # extreme parameter values
+    t[ext[:10], 28] = 0.0    # roughness 0
+    t[ext[10:20], 25] = 1.0  # metallic 1
+    t[ext[20:30], 32] = 1.0  # clearcoat 1
+    t[ext[30:], 21:24] = 0.0  # black base colour (Cdlum = 0 branch)
+    t[ext[:3], 3:9] = t[ext[:3], 0:3].repeat(2, 0).reshape(3, 6)  # degenerate triangles: p1 = p2 = p3
+    t[:, 34] = 1.0
+    mesh = rt.Mesh()
+    mesh.append(t)
+    nodes = mesh.buildBVHwithSAH(int(rng.choice([1, 3, 8, 20]))) if seed % 2 == 0 else mesh.buildBVH(int(rng.choice([2, 8])))
+    return mesh.triangles(), nodes, rng
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_triangle_soups(hdr_pair, seed):
+    """Random soups with random vertex normals and materials (extremes and degenerate triangles included), SAH and median
+    BVHs with several leaf sizes, cameras inside the geometry: image, statistics and closest hits equal the oracle's."""
+    tris, nodes, rng = _random_soup(seed)
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(float(rng.uniform(0, 360)), float(rng.uniform(-60, 60)), float(rng.uniform(0.2, 3.0)))
+    W, H, F = int(rng.randint(20, 90)), int(rng.randint(20, 70)), 3
+    for mode in (5, 4, 3):
+        d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam)
+        img = sc.render(d, 2, F)
+        ref, ost = O.render(tris, nodes, hdr, cache, W, H, mode, eye, cam, 2, F)
+        _assert_images_equal(img, ref, f"soup {seed}, mode {mode}")
+        assert sc.render_stats(d, 2, F) == ost
+    tri, dist = sc.primary_hits(rt.make_desc(W, H, eye=eye, camera_rotate=cam))
+    otri, odist = O.primary_hits(tris, nodes, W, H, eye, cam)
+    assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
