@@ -62,6 +62,7 @@ struct DevScene {
     const float4* ttri;   // 3 x float4 per triangle: (p1.xyz,p2.x) (p2.yz,p3.xy) (p3.z,N.xyz)
     const float* tris;    // Triangle_encoded[nT], the caller's layout
     const float4* nodes;  // 4 x float4 per internal node: (lAA,lBB.x) (lBB.yz,rAA.xy) (rAA.z,rBB) (lentry,rentry,-,-)
+    const float4* dmat;   // 4 x float4 per triangle: material-only terms of chapter 5's BRDF (MatPre), see rt_shade.h
     const float4* hdr;    // hdrMap as RGBX
     const float4* cache;  // hdrCache as RGBX
     int hdrW, hdrH;
@@ -279,6 +280,28 @@ __device__ __forceinline__ Mat load_material(const DevScene& sc, int tri) {
     return m;
 }
 
+__device__ __forceinline__ MatPre load_mat_pre(const DevScene& sc, int tri) {
+    const float4 a = sc.dmat[tri * 4 + 0], b = sc.dmat[tri * 4 + 1], c = sc.dmat[tri * 4 + 2], d = sc.dmat[tri * 4 + 3];
+    MatPre q;
+    q.Cspec0 = v3(a.x, a.y, a.z), q.Csheen = v3(a.w, b.x, b.y);
+    q.a2 = b.z, q.a2m1 = b.w;
+    q.g1_a = c.x, q.g1_a2 = c.y, q.g1_a2m1 = c.z, q.g1_k = c.w;
+    q.p_d = d.x, q.p_s = d.y, q.p_c = d.z;
+    return q;
+}
+// the material fields chapter 5's BRDF still reads per evaluation (the rest is in MatPre)
+__device__ __forceinline__ Mat load_material_eval5(const DevScene& sc, int tri) {
+    const float* T = sc.tris + (size_t)tri * 36 + 18;
+    Mat m;
+    m.emissive = v3(0);
+    m.baseColor = v3(T[3], T[4], T[5]);
+    m.subsurface = T[6], m.metallic = T[7], m.specular = 0.0f;
+    m.specularTint = 0.0f, m.roughness = T[10], m.anisotropic = 0.0f;
+    m.sheen = T[12], m.sheenTint = 0.0f, m.clearcoat = T[14];
+    m.clearcoatGloss = 0.0f;
+    return m;
+}
+
 // ---- E1: hdrColor / sampleHdr, f5:638-644, f4:159-165 --------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ vec3 envColor(const DevScene& sc, vec3 v) {
@@ -457,14 +480,17 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             const bool need_eval = isD || (h && kind == K_SHADOW && miss);
             if (STATS) { const int c_ = __popcll(__ballot(need_eval)); if (lane == 0) sg[0] += c_; }
             if (need_eval) {
-                const Mat mat = load_material(sc, surf_tri);
                 if (MODE == RT_MODE_CHAP5) {
-                    f_r = disney_eval<false, true>(V, N, L, v3(0), v3(0), mat, &pdf_brdf);
+                    const Mat mat = load_material_eval5(sc, surf_tri);
+                    const MatPre pre = load_mat_pre(sc, surf_tri);
+                    f_r = disney_eval5_pre(V, N, L, mat, pre, &pdf_brdf);
                 } else if (MODE == RT_MODE_CHAP4) {
+                    const Mat mat = load_material(sc, surf_tri);
                     vec3 tangent, bitangent;
                     getTagent(N, tangent, bitangent);
                     f_r = disney_eval<true, false>(V, N, L, tangent, bitangent, mat, nullptr);
                 } else {
+                    const Mat mat = load_material(sc, surf_tri);
                     f_r = mat.baseColor / PI_;
                 }
             }
@@ -557,7 +583,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             // ---- BRDF importance sampling (f5:883-895): after the env-visibility ray, or at once when it was skipped ---
             if (STATS) { const int c_ = __popcll(__ballot(isC || to_C)); if (lane == 0) sg[4] += c_; }
             if (MODE == RT_MODE_CHAP5 && (isC || to_C)) {
-                const Mat mat = load_material(sc, surf_tri);
+                const MatPre pre = load_mat_pre(sc, surf_tri);
                 const unsigned frame = (unsigned)(P.frame_begin + fidx);
                 const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
                 float su, sv;
@@ -565,7 +591,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 const float xi_1 = cp_rotate(su, cpu);
                 const float xi_2 = cp_rotate(sv, cpv);
                 const float xi_3 = rand01(seed);
-                const vec3 Ls = SampleBRDF(xi_1, xi_2, xi_3, V, N, mat);
+                const vec3 Ls = SampleBRDF_pre(xi_1, xi_2, xi_3, V, N, pre);
                 if (dot(N, Ls) <= 0.0f) {
                     fin = true;
                 } else {
@@ -893,6 +919,7 @@ struct rt_scene {
     int max_stack = 0;  // stack entries the deepest traversal can hold
     DevScene dev{};
     void* d_ttri = nullptr;
+    void* d_dmat = nullptr;
     void* d_tris = nullptr;
     void* d_nodes = nullptr;
     void* d_hdr = nullptr;
@@ -927,7 +954,7 @@ int rt_init(int device) {
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    (void)hipFree(s->d_ttri), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
+    (void)hipFree(s->d_ttri), (void)hipFree(s->d_dmat), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
     (void)hipFree(s->d_cache), (void)hipFree(s->d_spill), (void)hipFree(s->d_samples), (void)hipFree(s->d_queue);
     delete s;
 }
@@ -1008,6 +1035,22 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
         q[0] = t.p1.x, q[1] = t.p1.y, q[2] = t.p1.z, q[3] = t.p2.x, q[4] = t.p2.y, q[5] = t.p2.z;
         q[6] = t.p3.x, q[7] = t.p3.y, q[8] = t.p3.z, q[9] = Nn.x, q[10] = Nn.y, q[11] = Nn.z;
     }
+    std::vector<float> dmat((size_t)nT * 16, 0.0f);
+    for (int i = 0; i < nT; ++i) {
+        const rt_material& rm = ((const TriRec*)tris)[i].m;
+        Mat m;
+        m.emissive = v3(rm.emissive[0], rm.emissive[1], rm.emissive[2]);
+        m.baseColor = v3(rm.baseColor[0], rm.baseColor[1], rm.baseColor[2]);
+        m.subsurface = rm.subsurface, m.metallic = rm.metallic, m.specular = rm.specular;
+        m.specularTint = rm.specularTint, m.roughness = rm.roughness, m.anisotropic = rm.anisotropic;
+        m.sheen = rm.sheen, m.sheenTint = rm.sheenTint, m.clearcoat = rm.clearcoat;
+        m.clearcoatGloss = rm.clearcoatGloss;
+        const MatPre p = mat_precompute(m);
+        float* q = &dmat[(size_t)i * 16];
+        q[0] = p.Cspec0.x, q[1] = p.Cspec0.y, q[2] = p.Cspec0.z, q[3] = p.Csheen.x, q[4] = p.Csheen.y, q[5] = p.Csheen.z;
+        q[6] = p.a2, q[7] = p.a2m1, q[8] = p.g1_a, q[9] = p.g1_a2, q[10] = p.g1_a2m1, q[11] = p.g1_k;
+        q[12] = p.p_d, q[13] = p.p_s, q[14] = p.p_c;
+    }
 
     rt_scene* s = new rt_scene();
     s->device = g_device;
@@ -1027,6 +1070,8 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     if (nT > 0) {
         HIPCHK_S(hipMalloc(&s->d_ttri, ttri.size() * 4));
         HIPCHK_S(hipMemcpy(s->d_ttri, ttri.data(), ttri.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK_S(hipMalloc(&s->d_dmat, dmat.size() * 4));
+        HIPCHK_S(hipMemcpy(s->d_dmat, dmat.data(), dmat.size() * 4, hipMemcpyHostToDevice));
         HIPCHK_S(hipMalloc(&s->d_tris, (size_t)nT * 144));
         HIPCHK_S(hipMemcpy(s->d_tris, tris, (size_t)nT * 144, hipMemcpyHostToDevice));
     }
@@ -1048,6 +1093,7 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     }
 #undef HIPCHK_S
     s->dev.ttri = (const float4*)s->d_ttri;
+    s->dev.dmat = (const float4*)s->d_dmat;
     s->dev.tris = (const float*)s->d_tris;
     s->dev.nodes = (const float4*)s->d_nodes;
     s->dev.hdr = (const float4*)s->d_hdr;

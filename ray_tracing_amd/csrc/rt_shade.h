@@ -195,6 +195,92 @@ RT_HD vec3 disney_eval(vec3 V, vec3 N, vec3 L, vec3 X, vec3 Y, const Mat& m, flo
     return diffuse * (1.0f - m.metallic) + specular + clearcoat;
 }
 
+// ---- chapter 5 with the material-only terms taken out -----------------------------------------------------------------
+// Many terms of BRDF_Evaluate / BRDF_Pdf / SampleBRDF (f5:430-482, 662-699, 575-608) depend on the material alone.  The
+// device layer computes them once per triangle at scene creation (mat_precompute: the very expressions of disney_eval /
+// SampleBRDF above, fp32, same order) and the path loop reads them back: bit-identical values, ~200 fewer instructions per
+// shade pass (three vec3 / float quotients, a log, three weight quotients, several mixes).
+struct MatPre {
+    vec3 Cspec0, Csheen;
+    float a2, a2m1;                      // GTR2: alpha^2 and alpha^2 - 1 with alpha = max(0.001, roughness^2)
+    float g1_a, g1_a2, g1_a2m1, g1_k;    // GTR1: a = mix(0.1, 0.001, clearcoatGloss), a^2, a^2 - 1, PI * log(a^2)
+    float p_d, p_s, p_c;                 // lobe weights r / r_sum
+};
+RT_HD MatPre mat_precompute(const Mat& m) {
+    MatPre q;
+    const vec3 Cdlin = m.baseColor;
+    const float Cdlum = 0.3f * Cdlin.x + 0.6f * Cdlin.y + 0.1f * Cdlin.z;
+    const vec3 Ctint = (Cdlum > 0.0f) ? (Cdlin / Cdlum) : v3(1);
+    const vec3 Cspec = m.specular * mix3(v3(1), Ctint, m.specularTint);
+    q.Cspec0 = mix3(0.08f * Cspec, Cdlin, m.metallic);
+    q.Csheen = mix3(v3(1), Ctint, m.sheenTint);
+    const float alpha = fmax_(0.001f, sqr(m.roughness));
+    q.a2 = alpha * alpha;
+    q.a2m1 = q.a2 - 1.0f;
+    q.g1_a = mix_(0.1f, 0.001f, m.clearcoatGloss);
+    q.g1_a2 = q.g1_a * q.g1_a;
+    q.g1_a2m1 = q.g1_a2 - 1.0f;
+    q.g1_k = PI_ * det_log(q.g1_a2);
+    const float r_diffuse = (1.0f - m.metallic);
+    const float r_specular = 1.0f;
+    const float r_clearcoat = 0.25f * m.clearcoat;
+    const float r_sum = r_diffuse + r_specular + r_clearcoat;
+    q.p_d = r_diffuse / r_sum;
+    q.p_s = r_specular / r_sum;
+    q.p_c = r_clearcoat / r_sum;
+    return q;
+}
+// BRDF_Evaluate + BRDF_Pdf of chapter 5 (= disney_eval<false, true>) on the precomputed terms.  `m` needs baseColor,
+// roughness, subsurface, sheen, metallic, clearcoat only.
+RT_HD vec3 disney_eval5_pre(vec3 V, vec3 N, vec3 L, const Mat& m, const MatPre& q, float* pdf_out) {
+    const float NdotL = dot(N, L);
+    const float NdotV = dot(N, V);
+    if (NdotL < 0.0f || NdotV < 0.0f) {
+        *pdf_out = 0.0f;
+        return v3(0);
+    }
+    const vec3 H = normalize(L + V);
+    const float NdotH = dot(N, H);
+    const float LdotH = dot(L, H);
+    const vec3 Cdlin = m.baseColor;
+
+    const float Fd90 = 0.5f + 2.0f * m.roughness * LdotH * LdotH;
+    const float FL = SchlickFresnel(NdotL);
+    const float FV = SchlickFresnel(NdotV);
+    const float Fd = mix_(1.0f, Fd90, FL) * mix_(1.0f, Fd90, FV);
+    const float Fss90 = LdotH * LdotH * m.roughness;
+    const float Fss = mix_(1.0f, Fss90, FL) * mix_(1.0f, Fss90, FV);
+    const float ss = 1.25f * (Fss * (1.0f / (NdotL + NdotV) - 0.5f) + 0.5f);
+
+    const float FH = SchlickFresnel(LdotH);
+    const vec3 Fs = mix3(q.Cspec0, v3(1), FH);
+    const float t2 = 1.0f + q.a2m1 * NdotH * NdotH;  // GTR2
+    const float Ds = q.a2 / (PI_ * t2 * t2);
+    float Gs = smithG_GGX(NdotL, m.roughness);
+    Gs *= smithG_GGX(NdotV, m.roughness);
+    float Dr;  // GTR1
+    if (q.g1_a >= 1.0f) {
+        Dr = 1.0f / PI_;
+    } else {
+        const float t1 = 1.0f + q.g1_a2m1 * NdotH * NdotH;
+        Dr = q.g1_a2m1 / (q.g1_k * t1);
+    }
+    const float Fr = mix_(0.04f, 1.0f, FH);
+    const float Gr = smithG_GGX(NdotL, 0.25f) * smithG_GGX(NdotV, 0.25f);
+
+    const vec3 Fsheen = FH * m.sheen * q.Csheen;
+    const vec3 diffuse = (1.0f / PI_) * mix_(Fd, ss, m.subsurface) * Cdlin + Fsheen;
+    const vec3 specular = Gs * Fs * Ds;
+    const vec3 clearcoat = v3(0.25f * Gr * Fr * Dr * m.clearcoat);
+
+    const float pdf_diffuse = NdotL / PI_;
+    const float pdf_specular = Ds * NdotH / (4.0f * LdotH);
+    const float pdf_clearcoat = Dr * NdotH / (4.0f * LdotH);
+    const float pdf = q.p_d * pdf_diffuse + q.p_s * pdf_specular + q.p_c * pdf_clearcoat;
+    *pdf_out = fmax_(1e-10f, pdf);
+    return diffuse * (1.0f - m.metallic) + specular + clearcoat;
+}
+
 // ---- S1/S3/S4/S5: direction sampling, f5:509-608 -------------------------------------------------------------------
 RT_HD vec3 SampleHemisphereRand(unsigned& seed) {  // f4:110-115: z then phi
     const float z = rand01(seed);
@@ -245,6 +331,29 @@ RT_HD vec3 SampleBRDF(float xi_1, float xi_2, float xi_3, vec3 V, vec3 N, const 
     }
     const float cos_theta_h = sqrtf(num / den);
     // the azimuth and the radial factor
+    const float angle = diffuse ? (xi_2 * 2.0f * PI_) : (2.0f * PI_ * xi_1);
+    const float radial = sqrtf(diffuse ? xi_1 : fmax_(0.0f, 1.0f - cos_theta_h * cos_theta_h));
+    const float sin_a = det_sin(angle), cos_a = det_cos(angle);
+    const float x = radial * cos_a;
+    const float y = radial * sin_a;
+    const float z = diffuse ? sqrtf(1.0f - x * x - y * y) : cos_theta_h;
+    const vec3 T = toNormalHemisphere(v3(x, y, z), N);
+    return diffuse ? T : reflect(-V, T);
+}
+
+// SampleBRDF (above) on the precomputed terms.
+RT_HD vec3 SampleBRDF_pre(float xi_1, float xi_2, float xi_3, vec3 V, vec3 N, const MatPre& q) {
+    const float rd = xi_3;
+    const bool diffuse = rd <= q.p_d;
+    const bool specular = !diffuse && (q.p_d < rd && rd <= q.p_d + q.p_s);
+    const bool clearcoat = !diffuse && !specular && (q.p_d + q.p_s < rd);
+    if (!(diffuse || specular || clearcoat)) return v3(0, 1, 0);  // NaN weights
+    float num = 1.0f - xi_2, den = 1.0f + q.a2m1 * xi_2;
+    if (clearcoat) {
+        num = 1.0f - det_pow(q.g1_a2, 1.0f - xi_2);
+        den = 1.0f - q.g1_a2;
+    }
+    const float cos_theta_h = sqrtf(num / den);
     const float angle = diffuse ? (xi_2 * 2.0f * PI_) : (2.0f * PI_ * xi_1);
     const float radial = sqrtf(diffuse ? xi_1 : fmax_(0.0f, 1.0f - cos_theta_h * cos_theta_h));
     const float sin_a = det_sin(angle), cos_a = det_cos(angle);
