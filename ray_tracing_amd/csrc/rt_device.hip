@@ -65,6 +65,7 @@ struct DevScene {
     const float4* dmat;   // 4 x float4 per triangle: material-only terms of chapter 5's BRDF (MatPre), see rt_shade.h
     const float4* hdr;    // hdrMap as RGBX
     const float4* cache;  // hdrCache as RGBX
+    const float4* cdir;   // per hdrCache texel: the direction SampleHdr returns for it (f5:615-624), xyz-
     int hdrW, hdrH;
     int root_entry;       // packed entry of node 1
     int has_root;
@@ -568,8 +569,10 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (to_B) {
                 if (MODE == RT_MODE_CHAP5) {
                     const float r1 = rand01(seed), r2 = rand01(seed);
-                    const float4 ce = sc.cache[texel_index(r2, sc.hdrH) * sc.hdrW + texel_index(r1, sc.hdrW)];
-                    const vec3 Lh = hdrDirection(ce.x, ce.y);
+                    // SampleHdr (f5:612-625): the direction depends on the fetched texel alone, so it is tabulated per texel
+                    // at scene creation (hdrDirection on the texel's x, y: the same fp32 operations)
+                    const float4 ce = sc.cdir[texel_index(r2, sc.hdrH) * sc.hdrW + texel_index(r1, sc.hdrW)];
+                    const vec3 Lh = v3(ce.x, ce.y, ce.z);
                     if (dot(N, Lh) > 0.0f) {
                         S = hitP, d = Lh, kind = K_SHADOW, emit = true;
                     } else {
@@ -924,6 +927,7 @@ struct rt_scene {
     void* d_nodes = nullptr;
     void* d_hdr = nullptr;
     void* d_cache = nullptr;
+    void* d_cdir = nullptr;
     int* d_spill = nullptr;
     size_t spill_bytes = 0;
     float* d_samples = nullptr;  // sample buffer of the path loop (one launch: W x H x frames x RGB)
@@ -955,7 +959,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_ttri), (void)hipFree(s->d_dmat), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
-    (void)hipFree(s->d_cache), (void)hipFree(s->d_spill), (void)hipFree(s->d_samples), (void)hipFree(s->d_queue);
+    (void)hipFree(s->d_cache), (void)hipFree(s->d_cdir), (void)hipFree(s->d_spill), (void)hipFree(s->d_samples), (void)hipFree(s->d_queue);
     delete s;
 }
 
@@ -1089,6 +1093,12 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
             for (size_t i = 0; i < npx; ++i) tmp[i * 4] = hdr_cache[i * 3], tmp[i * 4 + 1] = hdr_cache[i * 3 + 1], tmp[i * 4 + 2] = hdr_cache[i * 3 + 2];
             HIPCHK_S(hipMalloc(&s->d_cache, npx * 16));
             HIPCHK_S(hipMemcpy(s->d_cache, tmp.data(), npx * 16, hipMemcpyHostToDevice));
+            for (size_t i = 0; i < npx; ++i) {
+                const vec3 L = hdrDirection(hdr_cache[i * 3], hdr_cache[i * 3 + 1]);
+                tmp[i * 4] = L.x, tmp[i * 4 + 1] = L.y, tmp[i * 4 + 2] = L.z;
+            }
+            HIPCHK_S(hipMalloc(&s->d_cdir, npx * 16));
+            HIPCHK_S(hipMemcpy(s->d_cdir, tmp.data(), npx * 16, hipMemcpyHostToDevice));
         }
     }
 #undef HIPCHK_S
@@ -1098,6 +1108,7 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     s->dev.nodes = (const float4*)s->d_nodes;
     s->dev.hdr = (const float4*)s->d_hdr;
     s->dev.cache = (const float4*)s->d_cache;
+    s->dev.cdir = (const float4*)s->d_cdir;
     s->dev.hdrW = hdrW, s->dev.hdrH = hdrH;
     s->dev.has_root = has_root ? 1 : 0;
     s->dev.root_entry = has_root ? entry[1] : 0;
