@@ -86,6 +86,7 @@ struct RenderParams {
     float cam[16];
     float* accum;
     float* samples;        // radiance samples of this launch, [frame - frame_begin][pixel][3]
+    const float2* sobol;   // this launch's sobolVec2(frame + 1, bounce) (f5:362-365, 883): [frame - frame_begin][bounce 0..3]
     unsigned* queue;       // work queues, one per XCD's band of tiles (64 B apart): the next unit (tile, frame group) of the band
     int unit_frames;       // frames per unit
     int* spill;            // global stack spill, [depth - kLdsDepth][thread]
@@ -375,6 +376,7 @@ __device__ __forceinline__ bool finite3(vec3 v) {
 }
 
 constexpr int kWave = 64;         // render_kernel: one wave64 per workgroup; work units are 8x8 pixel tiles x kUnitFrames frames
+constexpr int kMaxLaunchFrames = 1024;  // bound of RT_AMD_CHUNK (sizes the per-launch Sobol table)
 constexpr int kLaunchFrames = 32;  // frames per kernel launch (sample buffer = W x H x frames x 12 B)
 constexpr int kUnitFrames = 2;     // frames per work unit (one 8x8 tile x this many frames = 128 samples)
 constexpr size_t kMaxSampleBytes = (size_t)4 << 30;
@@ -587,12 +589,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (STATS) { const int c_ = __popcll(__ballot(isC || to_C)); if (lane == 0) sg[4] += c_; }
             if (MODE == RT_MODE_CHAP5 && (isC || to_C)) {
                 const MatPre pre = load_mat_pre(sc, surf_tri);
-                const unsigned frame = (unsigned)(P.frame_begin + fidx);
-                const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
-                float su, sv;
-                sobol_vec2(d_sobolV, bounce, gray, &su, &sv);
-                const float xi_1 = cp_rotate(su, cpu);
-                const float xi_2 = cp_rotate(sv, cpv);
+                const float2 sb = P.sobol[fidx * 4 + bounce];  // sobolVec2(frameCounter + 1, bounce): depends on (frame, bounce) only
+                const float xi_1 = cp_rotate(sb.x, cpu);
+                const float xi_2 = cp_rotate(sb.y, cpv);
                 const float xi_3 = rand01(seed);
                 const vec3 Ls = SampleBRDF_pre(xi_1, xi_2, xi_3, V, N, pre);
                 if (dot(N, Ls) <= 0.0f) {
@@ -845,6 +844,15 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     }
 }
 
+// sobolVec2(i, b) (f5:362-365) for the launch's frames (i = frameCounter + 1, f5:883) and the four bounces of chapter 5.
+__global__ void __launch_bounds__(128) sobol_table_kernel(float2* out, int frame_begin, int frame_count) {
+    const int t = blockIdx.x * 128 + threadIdx.x;
+    if (t >= frame_count * 4) return;
+    const unsigned frame = (unsigned)(frame_begin + t / 4);
+    const unsigned gray = (frame + 1u) ^ ((frame + 1u) >> 1);
+    out[t] = make_float2(sobol_dim(d_sobolV, 2 * (t & 3), gray), sobol_dim(d_sobolV, 2 * (t & 3) + 1, gray));
+}
+
 // The frame blend of f5:954-955 (or the plain sum of the spp-split multi-GPU mode): per pixel, over the launch's samples
 // in frame order.
 __global__ void __launch_bounds__(256) fold_kernel(const RenderParams P) {
@@ -932,6 +940,7 @@ struct rt_scene {
     size_t spill_bytes = 0;
     float* d_samples = nullptr;  // sample buffer of the path loop (one launch: W x H x frames x RGB)
     size_t samples_bytes = 0;
+    float2* d_sobol = nullptr;   // Sobol pairs of the current launch's frames (kMaxLaunchFrames x 4)
     unsigned* d_queue = nullptr; // work-queue counter of the path loop
     int cu_count = 0;
 };
@@ -959,7 +968,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_ttri), (void)hipFree(s->d_dmat), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
-    (void)hipFree(s->d_cache), (void)hipFree(s->d_cdir), (void)hipFree(s->d_spill), (void)hipFree(s->d_samples), (void)hipFree(s->d_queue);
+    (void)hipFree(s->d_cache), (void)hipFree(s->d_cdir), (void)hipFree(s->d_spill), (void)hipFree(s->d_samples), (void)hipFree(s->d_queue), (void)hipFree(s->d_sobol);
     delete s;
 }
 
@@ -1071,6 +1080,7 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     HIPCHK_S(hipSetDevice(s->device));
     HIPCHK_S(hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, s->device));
     HIPCHK_S(hipMalloc((void**)&s->d_queue, 8 * 16 * sizeof(unsigned)));
+    HIPCHK_S(hipMalloc((void**)&s->d_sobol, (size_t)kMaxLaunchFrames * 4 * sizeof(float2)));
     if (nT > 0) {
         HIPCHK_S(hipMalloc(&s->d_ttri, ttri.size() * 4));
         HIPCHK_S(hipMemcpy(s->d_ttri, ttri.data(), ttri.size() * 4, hipMemcpyHostToDevice));
@@ -1190,6 +1200,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
     // frames per kernel launch: bounded by the sample buffer (W x H x frames x RGB fp32, kept with the scene)
     int launch_frames = kLaunchFrames;
     if (const char* e = getenv("RT_AMD_CHUNK")) launch_frames = atoi(e) > 0 ? atoi(e) : kLaunchFrames;  // tuning knob
+    if (launch_frames > kMaxLaunchFrames) launch_frames = kMaxLaunchFrames;
     if (launch_frames > frame_count) launch_frames = frame_count;
     const size_t per_frame = (size_t)d->width * d->height * 3 * sizeof(float);
     while (launch_frames > 1 && per_frame * launch_frames > kMaxSampleBytes) launch_frames >>= 1;
@@ -1201,6 +1212,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         s->samples_bytes = per_frame * launch_frames;
     }
     P.samples = s->d_samples;
+    P.sobol = s->d_sobol;
     const bool spill = P.spill != nullptr;
     const int n_tiles = ((d->width + 7) / 8) * ((d->height + 7) / 8);
     const int fold_blocks = (int)(((size_t)d->width * d->height + 255) / 256);
@@ -1210,6 +1222,8 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         const long long n_units = (long long)n_tiles * ((P.frame_count + P.unit_frames - 1) / P.unit_frames);
         const int grid = (int)(n_units < blocks ? n_units : blocks);  // persistent waves: at most what the device holds
         HIPCHK(hipMemsetAsync(s->d_queue, 0, 8 * 16 * sizeof(unsigned), stream));
+        if (d->mode == RT_MODE_CHAP5)
+            hipLaunchKernelGGL(sobol_table_kernel, dim3((P.frame_count * 4 + 127) / 128), dim3(128), 0, stream, s->d_sobol, P.frame_begin, P.frame_count);
         TimedLaunch tl;
         HIPCHK(hipEventCreate(&tl.a));
         HIPCHK(hipEventCreate(&tl.b));

@@ -37,25 +37,6 @@ RT_HD float sobol_dim(const unsigned* __restrict__ V, int d, unsigned gray) {
     return (float)result * (1.0f / (float)0xFFFFFFFFu);
 }
 
-// sobolVec2(i, b), f5:362-365: dimensions 2b and 2b+1 for one Gray code.  Same XORs as two sobol_dim calls, but the table is
-// read four direction numbers per dimension at a time (16-byte loads, V 16-byte aligned) for as long as any lane of the wave
-// has bits left, so the loads of a group are in flight together instead of one dependent load per set bit.
-#ifdef __HIPCC__
-__device__ __forceinline__ void sobol_vec2(const unsigned* __restrict__ V, int b, unsigned gray, float* u, float* v) {
-    unsigned ru = 0u, rv = 0u;
-    const uint4* Vu = reinterpret_cast<const uint4*>(V + 64 * b);
-    const uint4* Vv = Vu + 8;
-    for (int g = 0; g < 8 && __any((gray >> (4 * g)) != 0u); ++g) {
-        const uint4 a = Vu[g], c = Vv[g];
-        const unsigned bits = gray >> (4 * g);
-        ru ^= ((bits & 1u) ? a.x : 0u) ^ ((bits & 2u) ? a.y : 0u) ^ ((bits & 4u) ? a.z : 0u) ^ ((bits & 8u) ? a.w : 0u);
-        rv ^= ((bits & 1u) ? c.x : 0u) ^ ((bits & 2u) ? c.y : 0u) ^ ((bits & 4u) ? c.z : 0u) ^ ((bits & 8u) ? c.w : 0u);
-    }
-    *u = (float)ru * (1.0f / (float)0xFFFFFFFFu);
-    *v = (float)rv * (1.0f / (float)0xFFFFFFFFu);
-}
-#endif
-
 // ---- R3: Cranley-Patterson rotation, f5:367-383 ------------------------------------------------------------------
 RT_HD void cp_shift(float pixx, float pixy, int width, int height, float* u, float* v) {
     unsigned pseed = pixel_seed(pixx, pixy, width, height, (unsigned)(114514 / 1919));
