@@ -288,7 +288,7 @@ __device__ __forceinline__ MatPre load_mat_pre(const DevScene& sc, int tri) {
     q.Cspec0 = v3(a.x, a.y, a.z), q.Csheen = v3(a.w, b.x, b.y);
     q.a2 = b.z, q.a2m1 = b.w;
     q.g1_a = c.x, q.g1_a2 = c.y, q.g1_a2m1 = c.z, q.g1_k = c.w;
-    q.p_d = d.x, q.p_s = d.y, q.p_c = d.z;
+    q.p_d = d.x, q.p_s = d.y, q.p_c = d.z, q.g1_lg = d.w;
     return q;
 }
 // the material fields chapter 5's BRDF still reads per evaluation (the rest is in MatPre)
@@ -1062,7 +1062,7 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
         float* q = &dmat[(size_t)i * 16];
         q[0] = p.Cspec0.x, q[1] = p.Cspec0.y, q[2] = p.Cspec0.z, q[3] = p.Csheen.x, q[4] = p.Csheen.y, q[5] = p.Csheen.z;
         q[6] = p.a2, q[7] = p.a2m1, q[8] = p.g1_a, q[9] = p.g1_a2, q[10] = p.g1_a2m1, q[11] = p.g1_k;
-        q[12] = p.p_d, q[13] = p.p_s, q[14] = p.p_c;
+        q[12] = p.p_d, q[13] = p.p_s, q[14] = p.p_c, q[15] = p.g1_lg;
     }
 
     rt_scene* s = new rt_scene();

@@ -185,6 +185,7 @@ struct MatPre {
     vec3 Cspec0, Csheen;
     float a2, a2m1;                      // GTR2: alpha^2 and alpha^2 - 1 with alpha = max(0.001, roughness^2)
     float g1_a, g1_a2, g1_a2m1, g1_k;    // GTR1: a = mix(0.1, 0.001, clearcoatGloss), a^2, a^2 - 1, PI * log(a^2)
+    float g1_lg;                         // log(a^2): the inner log of pow(a^2, 1 - xi) in the clearcoat lobe's sampler
     float p_d, p_s, p_c;                 // lobe weights r / r_sum
 };
 RT_HD MatPre mat_precompute(const Mat& m) {
@@ -201,7 +202,8 @@ RT_HD MatPre mat_precompute(const Mat& m) {
     q.g1_a = mix_(0.1f, 0.001f, m.clearcoatGloss);
     q.g1_a2 = q.g1_a * q.g1_a;
     q.g1_a2m1 = q.g1_a2 - 1.0f;
-    q.g1_k = PI_ * det_log(q.g1_a2);
+    q.g1_lg = det_log(q.g1_a2);
+    q.g1_k = PI_ * q.g1_lg;
     const float r_diffuse = (1.0f - m.metallic);
     const float r_specular = 1.0f;
     const float r_clearcoat = 0.25f * m.clearcoat;
@@ -331,7 +333,10 @@ RT_HD vec3 SampleBRDF_pre(float xi_1, float xi_2, float xi_3, vec3 V, vec3 N, co
     if (!(diffuse || specular || clearcoat)) return v3(0, 1, 0);  // NaN weights
     float num = 1.0f - xi_2, den = 1.0f + q.a2m1 * xi_2;
     if (clearcoat) {
-        num = 1.0f - det_pow(q.g1_a2, 1.0f - xi_2);
+        // det_pow(a^2, y) = exp(y * log(a^2)) with its x == 0 cases; the log comes from the table
+        const float y = 1.0f - xi_2;
+        const float pw = (q.g1_a2 == 0.0f) ? ((y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : u2f(0x7f800000u))) : det_exp(y * q.g1_lg);
+        num = 1.0f - pw;
         den = 1.0f - q.g1_a2;
     }
     const float cos_theta_h = sqrtf(num / den);
