@@ -1,0 +1,33 @@
+"""Termination soak: many launches of random sizes / frame ranges / modes / scenes / tuning knobs; prints progress lines.
+No oracle comparison (the parity tests do that): the point is that every launch drains its queue and returns."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import numpy as np
+import ray_tracing_amd as rt
+from ray_tracing_amd import scenes
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.RandomState(12345)
+hdr, cache = scenes.hdr_and_cache()
+pool = [scenes.small_scene(), scenes.chap5_scene(), scenes.chap4_scene(), scenes.synthetic_scene(9, 10),
+        (np.zeros((0, 36), np.float32), np.zeros((1, 12), np.float32))]
+objs = [rt.Scene(t, n, hdr, cache) for t, n in pool]
+t0 = time.time(); k = 0; paths = 0
+while time.time() - t0 < budget:
+    sc = objs[rng.randint(len(objs))]
+    W, H = int(rng.randint(1, 700)), int(rng.randint(1, 400))
+    F = int(rng.choice([1, 1, 2, 3, 7, 33, 70]))
+    mode = int(rng.choice([3, 4, 5]))
+    os.environ["RT_AMD_CHUNK"] = str(int(rng.choice([1, 2, 5, 32, 64])))
+    os.environ["RT_AMD_UNIT"] = str(int(rng.choice([1, 2, 3, 8])))
+    os.environ["RT_AMD_REFILL"] = str(int(rng.choice([1, 16, 48, 64])))
+    os.environ["RT_AMD_LEAF"] = str(int(rng.choice([1, 8, 64])))
+    os.environ["RT_AMD_WAIT"] = str(int(rng.choice([1, 100, 4000, 10**8])))
+    eye, cam = rt.camera(float(rng.uniform(0, 360)), float(rng.uniform(-89, 89)), float(rng.uniform(0.05, 8)))
+    d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam, accumulate=int(rng.randint(2)))
+    img = sc.render(d, int(rng.randint(0, 5000)), F)
+    assert img.shape == (H, W, 3)
+    k += 1; paths += W * H * F
+    if k % 50 == 0:
+        print(f"{k} launches, {paths / 1e6:.0f} Mpaths, {time.time() - t0:.0f} s", flush=True)
+print(f"soak ok: {k} launches, {paths / 1e6:.0f} Mpaths in {time.time() - t0:.0f} s")
