@@ -478,3 +478,23 @@ def test_random_triangle_soups(hdr_pair, seed):
     tri, dist = sc.primary_hits(rt.make_desc(W, H, eye=eye, camera_rotate=cam))
     otri, odist = O.primary_hits(tris, nodes, W, H, eye, cam)
     assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
+
+
+def test_scene_without_environment_map(scene_small):
+    """Chapter 3 of the reference binds no HDR map: escaped rays add nothing and only emitters light the picture.  Chapters 3/4
+    render such a scene like the oracle; chapter 5 samples the map's cache every bounce (f5:862), so it is refused."""
+    tris, nodes = scene_small
+    tris = tris.copy()
+    tris[::7, 18:21] = (3.0, 2.5, 2.0)  # every 7th triangle emits
+    sc = rt.Scene(tris, nodes)
+    eye, cam = rt.camera(30.0, 10.0, 3.0)
+    W, H, F = 72, 40, 3
+    for mode in (3, 4):
+        d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam)
+        img = sc.render(d, 0, F)
+        ref, ost = O.render(tris, nodes, None, None, W, H, mode, eye, cam, 0, F)
+        _assert_images_equal(img, ref, f"no hdr, mode {mode}")
+        assert img.max() > 0.0 and (img == 0.0).any()
+        assert sc.render_stats(d, 0, F) == ost
+    with pytest.raises(rt.RtError):
+        sc.render(rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam), 0, 1)
