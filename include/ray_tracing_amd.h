@@ -119,7 +119,10 @@ int rt_chap1_to_rgb8(const double* image, int width, int height, unsigned char* 
  * Device layer (HIP, gfx950): the per-pixel path loop.
  * ------------------------------------------------------------------------------------------------------------------ */
 
-/* Replaces the GL context: binds the calling thread's library state to HIP device `device`. */
+/* Replaces the GL context: binds the calling thread's library state to HIP device `device` and makes it current.
+ * Scenes created afterwards on this thread live on that device.  Without rt_init, rt_scene_create adopts the device
+ * that is current on the calling thread (hipGetDevice).  Every other entry point makes its scene's device current for
+ * the duration of the call and restores the caller's current device before it returns. */
 int rt_init(int device);
 
 /* Replaces the TBO / texture uploads of c5:881-909.  `tris` = Triangle_encoded[nT] (36 floats each), `nodes` =
@@ -136,7 +139,7 @@ enum { RT_ACCUM_RUNNING_MEAN = 0, /* color = mix(last, color, 1/(frameCounter+1)
 
 /* The uniforms of f5:8-23 / c5:726-730, 923-928. */
 typedef struct rt_render_desc {
-    int32_t width, height;     /* uniform width,height */
+    int32_t width, height;     /* uniform width,height; 1..65535 x 1..32767 */
     int32_t mode;              /* RT_MODE_* */
     int32_t max_bounce;        /* literal 4 at f5:949, 6 at f4:564 / f3; <=0 selects the reference literal */
     int32_t accumulate;        /* RT_ACCUM_* */
@@ -157,6 +160,18 @@ int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int 
 int rt_primary_hits(rt_scene* s, const rt_render_desc* d, int32_t* tri_index_host, float* distance_host);
 int rt_primary_hits_device(rt_scene* s, const rt_render_desc* d, int32_t* tri_index_dev, float* distance_dev,
                            void* hip_stream);
+
+/* Scheduling knobs of the path loop, per scene (they change how the work is cut, never the image: tested).  Fields <= 0
+ * select the default; rt_scene_set_tuning(s, NULL) restores all defaults.  No counterpart in the reference. */
+typedef struct rt_tuning {
+    int32_t launch_frames;     /* frames per kernel launch (sample buffer = W*H*launch_frames*12 B); default 32, max 1024 */
+    int32_t unit_frames;       /* frames per work unit (one 8x8 tile x unit_frames samples); default 2 */
+    int32_t leaf_lanes;        /* lanes holding a leaf that trigger a cooperative leaf pass; default 8 */
+    int32_t shade_lanes;       /* lanes waiting for the shade pass that trigger it; default 48 */
+    int32_t wait_budget;       /* lane-passes spent waiting that trigger the shade pass; default 4000 */
+} rt_tuning;
+int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out);
+int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t);
 
 /* Traversal statistics of a render (same rays as rt_render): totals over all hitBVH invocations. */
 typedef struct rt_trace_stats {

@@ -22,6 +22,32 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build it with `make -C ray_tracing_amd/csrc` (or __graft_entry__.build()); "
         "ray_tracing_amd has no fallback path")
 
+
+
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and ask for it by
+    file name, so a process that loaded /opt/rocm's copy first ends up with TWO runtimes and torch then finds no GPU.  When
+    torch is installed, load its copy before this library: both then share one runtime whatever the import order.  torch
+    itself is not imported; without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+_share_torch_hip_runtime()
 _lib = C.CDLL(LIB_PATH)
 
 RT_MODE_CHAP3, RT_MODE_CHAP4, RT_MODE_CHAP5 = 3, 4, 5
@@ -63,6 +89,11 @@ class TraceStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class Tuning(C.Structure):
+    """rt_tuning: scheduling knobs of the path loop (they never change the image)."""
+    _fields_ = [(n, C.c_int32) for n in ("launch_frames", "unit_frames", "leaf_lanes", "shade_lanes", "wait_budget")]
+
+
 class RtError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"[rt_status {code}] {msg}")
@@ -92,6 +123,8 @@ _lib.rt_scene_destroy.argtypes = [C.c_void_p]
 _lib.rt_scene_destroy.restype = None
 _lib.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p]
 _lib.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+_lib.rt_scene_get_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+_lib.rt_scene_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
 _lib.rt_primary_hits.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p]
 _lib.rt_primary_hits_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
@@ -269,6 +302,21 @@ class Scene:
         """Same on device memory (accum_ptr = device address of W*H*3 fp32), asynchronous on `stream`."""
         _check(_lib.rt_render_device(self._h, C.byref(desc), frame_begin, frame_count, C.c_void_p(accum_ptr),
                                      C.c_void_p(stream)))
+
+    def tuning(self) -> Tuning:
+        t = Tuning()
+        _check(_lib.rt_scene_get_tuning(self._h, C.byref(t)))
+        return t
+
+    def set_tuning(self, **kw):
+        """Set some knobs of rt_tuning (others keep their value); set_tuning() with no argument restores the defaults."""
+        if not kw:
+            _check(_lib.rt_scene_set_tuning(self._h, None))
+            return
+        t = self.tuning()
+        for k, v in kw.items():
+            setattr(t, k, int(v))
+        _check(_lib.rt_scene_set_tuning(self._h, C.byref(t)))
 
     def primary_hits(self, desc: RenderDesc):
         """Chapter-2 hitBVH (c2:490-513) for the un-jittered camera rays: (tri index int32, distance fp32)."""

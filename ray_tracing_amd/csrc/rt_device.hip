@@ -380,6 +380,7 @@ constexpr int kMaxLaunchFrames = 1024;  // bound of RT_AMD_CHUNK (sizes the per-
 constexpr int kLaunchFrames = 32;  // frames per kernel launch (sample buffer = W x H x frames x 12 B)
 constexpr int kUnitFrames = 2;     // frames per work unit (one 8x8 tile x this many frames = 128 samples)
 constexpr size_t kMaxSampleBytes = (size_t)4 << 30;
+constexpr int kMaxWidth = 65535, kMaxHeight = 32767;  // a pixel travels as (x | y << 16) in one int
 constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
 
 template <bool SPILL>
@@ -920,6 +921,23 @@ static void remember_launch(const TimedLaunch& tl) {
 }
 static thread_local int g_device = -1;
 
+// Makes the scene's device current for the duration of an entry point and restores the caller's afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == device) || (hipSetDevice(device) == hipSuccess);
+        if (prev == device) prev = -1;  // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define GUARD_DEVICE(s_)                                                                                   \
+    DeviceGuard guard_((s_)->device);                                                                      \
+    if (!guard_.ok) return set_error(RT_ERR_HIP, "cannot make device %d current (%s:%d)", (s_)->device, __FILE__, __LINE__)
+
 }  // namespace rta
 
 using namespace rta;
@@ -942,7 +960,10 @@ struct rt_scene {
     size_t samples_bytes = 0;
     float2* d_sobol = nullptr;   // Sobol pairs of the current launch's frames (kMaxLaunchFrames x 4)
     unsigned* d_queue = nullptr; // work-queue counter of the path loop
+    float* d_frame = nullptr;    // rt_render: device copy of the caller's host accumulation buffer
+    size_t frame_bytes = 0;
     int cu_count = 0;
+    rt_tuning tuning{kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget};
 };
 
 static int f2i_checked(float f, int* out) {
@@ -966,7 +987,8 @@ int rt_init(int device) {
 
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
-    (void)hipSetDevice(s->device);
+    DeviceGuard guard(s->device);
+    (void)hipFree(s->d_frame);
     (void)hipFree(s->d_ttri), (void)hipFree(s->d_dmat), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
     (void)hipFree(s->d_cache), (void)hipFree(s->d_cdir), (void)hipFree(s->d_spill), (void)hipFree(s->d_samples), (void)hipFree(s->d_queue), (void)hipFree(s->d_sobol);
     delete s;
@@ -982,8 +1004,10 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     if ((hdr_map || hdr_cache) && (hdrW <= 0 || hdrH <= 0 || (long long)hdrW * hdrH > (1ll << 28)))
         return set_error(RT_ERR_INVALID_ARG, "rt_scene_create: bad HDR size %dx%d", hdrW, hdrH);
     if (hdr_cache && !hdr_map) return set_error(RT_ERR_INVALID_ARG, "rt_scene_create: hdr_cache without hdr_map");
-    if (g_device < 0) {
-        const int rc = rt_init(0);
+    if (g_device < 0) {  // no rt_init on this thread: adopt the caller's current device
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+        const int rc = rt_init(cur);
         if (rc != RT_OK) return rc;
     }
 
@@ -1077,7 +1101,8 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
         hipError_t e_ = (expr);                                                                                      \
         if (e_ != hipSuccess) return fail(set_error(RT_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__)); \
     } while (0)
-    HIPCHK_S(hipSetDevice(s->device));
+    DeviceGuard guard(s->device);  // the caller's current device is restored on return
+    if (!guard.ok) return fail(set_error(RT_ERR_HIP, "rt_scene_create: cannot make device %d current", s->device));
     HIPCHK_S(hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, s->device));
     HIPCHK_S(hipMalloc((void**)&s->d_queue, 8 * 16 * sizeof(unsigned)));
     HIPCHK_S(hipMalloc((void**)&s->d_sobol, (size_t)kMaxLaunchFrames * 4 * sizeof(float2)));
@@ -1132,47 +1157,59 @@ namespace rta {
 
 static int check_desc(const rt_scene* s, const rt_render_desc* d, const char* who) {
     if (!s || !d) return set_error(RT_ERR_INVALID_ARG, "%s: NULL scene or descriptor", who);
-    if (d->width <= 0 || d->height <= 0 || (long long)d->width * d->height > (1ll << 30))
-        return set_error(RT_ERR_INVALID_ARG, "%s: bad image size %dx%d", who, d->width, d->height);
+    // the path loop carries a pixel as (x | y << 16) in one int: x < 2^16, y < 2^15
+    if (d->width <= 0 || d->height <= 0 || d->width > kMaxWidth || d->height > kMaxHeight)
+        return set_error(RT_ERR_INVALID_ARG, "%s: bad image size %dx%d (1..%d x 1..%d)", who, d->width, d->height, kMaxWidth, kMaxHeight);
     return RT_OK;
 }
 
-static int fill_params(rt_scene* s, const rt_render_desc* d, RenderParams* P, int* blocks, bool render) {
+// Device memory a launch needs beside the scene, the inputs and the outputs.  rt_render* takes it from buffers kept with
+// the scene (allocated / grown on demand).
+struct Workspace {
+    unsigned* queue = nullptr;     // 8 work-queue counters, 64 B apart
+    float2* sobol = nullptr;       // kMaxLaunchFrames x 4 Sobol pairs
+    float* samples = nullptr;      // launch_frames x W x H x RGB
+    int launch_frames = 0;         // frames per kernel launch that `samples` holds
+    int* spill = nullptr;          // global part of the traversal stacks (deep trees only)
+    long long spill_stride = 0;
+    bool timed = false;            // bracket the path-loop kernel with HIP events (creates events: allocating callers only)
+};
+
+static void fill_params(const rt_scene* s, const rt_render_desc* d, RenderParams* P) {
     memset(P, 0, sizeof(*P));
     P->sc = s->dev;
     P->width = d->width, P->height = d->height;
     P->accumulate = d->accumulate;
     memcpy(P->eye, d->eye, sizeof(P->eye));
     memcpy(P->cam, d->camera_rotate, sizeof(P->cam));
-    // render_kernel: persistent single-wave workgroups, as many as the device can hold (32 wave slots per CU is the
-    // hardware ceiling; workgroups beyond the kernel's real occupancy start late, find the queue empty and leave);
-    // primary_kernel: 256 threads per 16x16 tile
-    const int block_threads = render ? kWave : kBlock;
-    *blocks = render ? s->cu_count * 32 : ((d->width + 15) / 16) * ((d->height + 15) / 16);
-    P->leaf_lanes = kLeafLanes;
-    if (const char* e = getenv("RT_AMD_LEAF")) P->leaf_lanes = atoi(e) > 0 ? atoi(e) : kLeafLanes;  // tuning knob
-    P->wait_budget = kWaitBudget;
-    if (const char* e = getenv("RT_AMD_WAIT")) P->wait_budget = atoi(e) > 0 ? atoi(e) : kWaitBudget;  // tuning knob
-    P->refill = kHandlerLanes;
-    if (const char* e = getenv("RT_AMD_REFILL")) P->refill = atoi(e) > 0 ? atoi(e) : kHandlerLanes;  // tuning knob
-    if (s->max_stack > kLdsDepth) {  // deep tree: per-thread global spill beyond the LDS part of the stack
-        const size_t threads = (size_t)*blocks * block_threads;
-        const size_t bytes = threads * (size_t)(s->max_stack - kLdsDepth) * sizeof(int);
-        if (bytes > s->spill_bytes) {
-            (void)hipFree(s->d_spill);
-            s->d_spill = nullptr, s->spill_bytes = 0;
-            HIPCHK(hipMalloc((void**)&s->d_spill, bytes));
-            s->spill_bytes = bytes;
-        }
-        P->spill = s->d_spill;
-        P->spill_stride = (long long)threads;
+    P->leaf_lanes = s->tuning.leaf_lanes;
+    P->wait_budget = s->tuning.wait_budget;
+    P->refill = s->tuning.shade_lanes;
+    P->unit_frames = s->tuning.unit_frames;
+}
+
+// render_kernel: persistent single-wave workgroups, as many as the device can hold (32 wave slots per CU is the hardware
+// ceiling; workgroups beyond the kernel's real occupancy start late, find the queue empty and leave)
+static int render_blocks(const rt_scene* s) { return s->cu_count * 32; }
+// bytes of global stack spill `threads` lanes need on this scene (0: the tree fits the LDS part of the stack)
+static size_t spill_bytes_needed(const rt_scene* s, size_t threads) {
+    return s->max_stack > kLdsDepth ? threads * (size_t)(s->max_stack - kLdsDepth) * sizeof(int) : 0;
+}
+static int grow_scene_spill(rt_scene* s, size_t threads, int** spill, long long* stride) {
+    const size_t bytes = spill_bytes_needed(s, threads);
+    *spill = nullptr, *stride = 0;
+    if (bytes == 0) return RT_OK;
+    if (bytes > s->spill_bytes) {
+        (void)hipFree(s->d_spill);
+        s->d_spill = nullptr, s->spill_bytes = 0;
+        HIPCHK(hipMalloc((void**)&s->d_spill, bytes));
+        s->spill_bytes = bytes;
     }
+    *spill = s->d_spill, *stride = (long long)threads;
     return RT_OK;
 }
 
-template <bool STATS>
-static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_dev,
-                         unsigned long long* stats_dev, hipStream_t stream) {
+static int check_render_args(const rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, const float* accum_dev) {
     int rc = check_desc(s, d, "rt_render");
     if (rc != RT_OK) return rc;
     if (!accum_dev) return set_error(RT_ERR_INVALID_ARG, "rt_render: accum is NULL");
@@ -1183,36 +1220,28 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         return set_error(RT_ERR_INVALID_ARG, "rt_render: unknown accumulate mode %d", d->accumulate);
     if (d->mode == RT_MODE_CHAP5 && !s->d_cache)
         return set_error(RT_ERR_INVALID_ARG, "rt_render: mode 5 needs hdr_map and hdr_cache in the scene");
-    if (frame_count == 0) return RT_OK;
-    HIPCHK(hipSetDevice(s->device));
+    const int mb = d->max_bounce > 0 ? d->max_bounce : (d->mode == RT_MODE_CHAP5 ? 4 : 6);
+    if (d->mode == RT_MODE_CHAP5 && mb > 4)  // sobolVec2(i, bounce) reads V[(2*bounce+1)*32 + j] of the 8-dimension table (f5:339, 883)
+        return set_error(RT_ERR_INVALID_ARG, "rt_render: mode 5 supports max_bounce <= 4 (the reference's Sobol table has 8 dimensions), got %d", mb);
+    return RT_OK;
+}
+
+// The launches of one rt_render* call on a prepared workspace (arguments already checked, scene's device current).
+// Allocates nothing unless ws.timed (HIP events).
+template <bool STATS>
+static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_dev,
+                         unsigned long long* stats_dev, hipStream_t stream, const Workspace& ws) {
     RenderParams P;
-    int blocks;
-    rc = fill_params(s, d, &P, &blocks, true);
-    if (rc != RT_OK) return rc;
+    fill_params(s, d, &P);
     P.max_bounce = d->max_bounce > 0 ? d->max_bounce : (d->mode == RT_MODE_CHAP5 ? 4 : 6);
-    if (d->mode == RT_MODE_CHAP5 && P.max_bounce > 4)  // sobolVec2(i, bounce) reads V[(2*bounce+1)*32 + j] of the 8-dimension table (f5:339, 883)
-        return set_error(RT_ERR_INVALID_ARG, "rt_render: mode 5 supports max_bounce <= 4 (the reference's Sobol table has 8 dimensions), got %d", P.max_bounce);
     P.accum = accum_dev;
     P.stats = stats_dev;
-    P.queue = s->d_queue;
-    P.unit_frames = kUnitFrames;
-    if (const char* e = getenv("RT_AMD_UNIT")) P.unit_frames = atoi(e) > 0 ? atoi(e) : kUnitFrames;  // tuning knob
-    // frames per kernel launch: bounded by the sample buffer (W x H x frames x RGB fp32, kept with the scene)
-    int launch_frames = kLaunchFrames;
-    if (const char* e = getenv("RT_AMD_CHUNK")) launch_frames = atoi(e) > 0 ? atoi(e) : kLaunchFrames;  // tuning knob
-    if (launch_frames > kMaxLaunchFrames) launch_frames = kMaxLaunchFrames;
-    if (launch_frames > frame_count) launch_frames = frame_count;
-    const size_t per_frame = (size_t)d->width * d->height * 3 * sizeof(float);
-    while (launch_frames > 1 && per_frame * launch_frames > kMaxSampleBytes) launch_frames >>= 1;
-    if (per_frame * launch_frames > s->samples_bytes) {
-        (void)hipFree(s->d_samples);
-        s->d_samples = nullptr, s->samples_bytes = 0;
-        if (hipMalloc((void**)&s->d_samples, per_frame * launch_frames) != hipSuccess)
-            return set_error(RT_ERR_OOM, "rt_render: cannot allocate the %zu-byte sample buffer", per_frame * launch_frames);
-        s->samples_bytes = per_frame * launch_frames;
-    }
-    P.samples = s->d_samples;
-    P.sobol = s->d_sobol;
+    P.queue = ws.queue;
+    P.samples = ws.samples;
+    P.sobol = ws.sobol;
+    P.spill = ws.spill, P.spill_stride = ws.spill_stride;
+    const int blocks = render_blocks(s);
+    const int launch_frames = ws.launch_frames;
     const bool spill = P.spill != nullptr;
     const int n_tiles = ((d->width + 7) / 8) * ((d->height + 7) / 8);
     const int fold_blocks = (int)(((size_t)d->width * d->height + 255) / 256);
@@ -1221,13 +1250,16 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         P.frame_count = frame_count - done < launch_frames ? frame_count - done : launch_frames;
         const long long n_units = (long long)n_tiles * ((P.frame_count + P.unit_frames - 1) / P.unit_frames);
         const int grid = (int)(n_units < blocks ? n_units : blocks);  // persistent waves: at most what the device holds
-        HIPCHK(hipMemsetAsync(s->d_queue, 0, 8 * 16 * sizeof(unsigned), stream));
+        HIPCHK(hipMemsetAsync(ws.queue, 0, 8 * 16 * sizeof(unsigned), stream));
         if (d->mode == RT_MODE_CHAP5)
-            hipLaunchKernelGGL(sobol_table_kernel, dim3((P.frame_count * 4 + 127) / 128), dim3(128), 0, stream, s->d_sobol, P.frame_begin, P.frame_count);
-        TimedLaunch tl;
-        HIPCHK(hipEventCreate(&tl.a));
-        HIPCHK(hipEventCreate(&tl.b));
-        HIPCHK(hipEventRecord(tl.a, stream));
+            hipLaunchKernelGGL(sobol_table_kernel, dim3((P.frame_count * 4 + 127) / 128), dim3(128), 0, stream, ws.sobol, P.frame_begin, P.frame_count);
+        TimedLaunch tl{};
+        const bool timed = ws.timed && !STATS;
+        if (timed) {
+            HIPCHK(hipEventCreate(&tl.a));
+            HIPCHK(hipEventCreate(&tl.b));
+            HIPCHK(hipEventRecord(tl.a, stream));
+        }
 #define LAUNCH(MODE_)                                                                                 \
     do {                                                                                              \
         if (spill)                                                                                    \
@@ -1243,11 +1275,9 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
             LAUNCH(RT_MODE_CHAP3);
 #undef LAUNCH
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(tl.b, stream));
-        if (!STATS) {
+        if (timed) {
+            HIPCHK(hipEventRecord(tl.b, stream));
             remember_launch(tl);
-        } else {
-            (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
         }
         hipLaunchKernelGGL(fold_kernel, dim3(fold_blocks), dim3(256), 0, stream, P);
         HIPCHK(hipGetLastError());
@@ -1255,42 +1285,95 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
     return RT_OK;
 }
 
+// Workspace of the allocating entry points: buffers kept with the scene, grown when a call needs more.
+static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count, Workspace* ws) {
+    ws->queue = s->d_queue;
+    ws->sobol = s->d_sobol;
+    int rc = grow_scene_spill(s, (size_t)render_blocks(s) * kWave, &ws->spill, &ws->spill_stride);
+    if (rc != RT_OK) return rc;
+    // frames per kernel launch: bounded by the sample buffer (W x H x frames x RGB fp32)
+    int launch_frames = s->tuning.launch_frames;
+    if (launch_frames > frame_count) launch_frames = frame_count;
+    const size_t per_frame = (size_t)d->width * d->height * 3 * sizeof(float);
+    while (launch_frames > 1 && per_frame * launch_frames > kMaxSampleBytes) launch_frames >>= 1;
+    if (per_frame * launch_frames > s->samples_bytes) {
+        (void)hipFree(s->d_samples);
+        s->d_samples = nullptr, s->samples_bytes = 0;
+        if (hipMalloc((void**)&s->d_samples, per_frame * launch_frames) != hipSuccess)
+            return set_error(RT_ERR_OOM, "rt_render: cannot allocate the %zu-byte sample buffer", per_frame * launch_frames);
+        s->samples_bytes = per_frame * launch_frames;
+    }
+    ws->samples = s->d_samples;
+    ws->launch_frames = launch_frames;
+    ws->timed = true;
+    return RT_OK;
+}
+
 }  // namespace rta
 
 extern "C" {
 
+int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out) {
+    if (!s || !out) return set_error(RT_ERR_INVALID_ARG, "rt_scene_get_tuning: NULL argument");
+    *out = s->tuning;
+    return RT_OK;
+}
+
+int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
+    if (!s) return set_error(RT_ERR_INVALID_ARG, "rt_scene_set_tuning: NULL scene");
+    const rt_tuning def = {kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget};
+    rt_tuning n = t ? *t : def;
+    if (n.launch_frames <= 0) n.launch_frames = def.launch_frames;
+    if (n.unit_frames <= 0) n.unit_frames = def.unit_frames;
+    if (n.leaf_lanes <= 0) n.leaf_lanes = def.leaf_lanes;
+    if (n.shade_lanes <= 0) n.shade_lanes = def.shade_lanes;
+    if (n.wait_budget <= 0) n.wait_budget = def.wait_budget;
+    if (n.launch_frames > kMaxLaunchFrames) n.launch_frames = kMaxLaunchFrames;
+    if (n.unit_frames > kMaxLaunchFrames) n.unit_frames = kMaxLaunchFrames;
+    if (n.leaf_lanes > kWave) n.leaf_lanes = kWave;
+    if (n.shade_lanes > kWave) n.shade_lanes = kWave;
+    s->tuning = n;
+    return RT_OK;
+}
+
 int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_dev, void* stream) {
-    return launch_render<false>(s, d, frame_begin, frame_count, accum_dev, nullptr, (hipStream_t)stream);
+    int rc = check_render_args(s, d, frame_begin, frame_count, accum_dev);
+    if (rc != RT_OK) return rc;
+    if (frame_count == 0) return RT_OK;
+    GUARD_DEVICE(s);
+    Workspace ws;
+    rc = scene_workspace(s, d, frame_count, &ws);
+    if (rc != RT_OK) return rc;
+    return launch_render<false>(s, d, frame_begin, frame_count, accum_dev, nullptr, (hipStream_t)stream, ws);
 }
 
 int rt_render(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_host) {
     int rc = check_desc(s, d, "rt_render");
     if (rc != RT_OK) return rc;
     if (!accum_host) return set_error(RT_ERR_INVALID_ARG, "rt_render: accum is NULL");
-    HIPCHK(hipSetDevice(s->device));
+    GUARD_DEVICE(s);
     const size_t bytes = (size_t)d->width * d->height * 3 * sizeof(float);
-    float* dev = nullptr;
-    HIPCHK(hipMalloc((void**)&dev, bytes));
-    hipError_t e = hipMemcpy(dev, accum_host, bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        rc = rt_render_device(s, d, frame_begin, frame_count, dev, nullptr);
-        if (rc == RT_OK) {
-            e = hipDeviceSynchronize();
-            if (e == hipSuccess) e = hipMemcpy(accum_host, dev, bytes, hipMemcpyDeviceToHost);
-        }
+    if (bytes > s->frame_bytes) {  // the device copy of lastFrame is kept with the scene: later calls allocate nothing
+        (void)hipFree(s->d_frame);
+        s->d_frame = nullptr, s->frame_bytes = 0;
+        HIPCHK(hipMalloc((void**)&s->d_frame, bytes));
+        s->frame_bytes = bytes;
     }
-    (void)hipFree(dev);
+    HIPCHK(hipMemcpyAsync(s->d_frame, accum_host, bytes, hipMemcpyHostToDevice, nullptr));
+    rc = rt_render_device(s, d, frame_begin, frame_count, s->d_frame, nullptr);
     if (rc != RT_OK) return rc;
-    if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_render: %s", hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(accum_host, s->d_frame, bytes, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
     return RT_OK;
 }
 
 int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out) {
-    int rc = check_desc(s, d, "rt_render_stats");
-    if (rc != RT_OK) return rc;
     if (!out) return set_error(RT_ERR_INVALID_ARG, "rt_render_stats: out is NULL");
-    HIPCHK(hipSetDevice(s->device));
-    const size_t bytes = (size_t)d->width * d->height * 3 * sizeof(float);
+    const size_t bytes = (s && d && d->width > 0 && d->height > 0) ? (size_t)d->width * d->height * 3 * sizeof(float) : 0;
+    float dummy = 0.0f;
+    int rc = check_render_args(s, d, frame_begin, frame_count, &dummy);
+    if (rc != RT_OK) return rc;
+    GUARD_DEVICE(s);
     float* dev = nullptr;
     unsigned long long* st = nullptr;
     HIPCHK(hipMalloc((void**)&dev, bytes));
@@ -1298,8 +1381,10 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     if (e == hipSuccess) e = hipMemset(dev, 0, bytes);
     if (e == hipSuccess) e = hipMemset(st, 0, 26 * sizeof(unsigned long long));
     unsigned long long h[26] = {0};
-    if (e == hipSuccess) {
-        rc = launch_render<true>(s, d, frame_begin, frame_count, dev, st, nullptr);
+    if (e == hipSuccess && frame_count > 0) {
+        Workspace ws;
+        rc = scene_workspace(s, d, frame_count, &ws);
+        if (rc == RT_OK) rc = launch_render<true>(s, d, frame_begin, frame_count, dev, st, nullptr, ws);
         if (rc == RT_OK) {
             e = hipDeviceSynchronize();
             if (e == hipSuccess) e = hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
@@ -1308,7 +1393,7 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     (void)hipFree(dev), (void)hipFree(st);
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_render_stats: %s", hipGetErrorString(e));
-    if (getenv("RT_AMD_DIAG")) {
+    if (getenv("RT_AMD_DIAG")) {  // diagnostics print only; no effect on what is computed
         static const char* sn[7] = {"BRDF eval", "env lookup", "finish hit", "bounce start", "BRDF sampling", "end of sample", "ray prologue"};
         for (int k = 0; k < 7; ++k)
             fprintf(stderr, "[rt diag] shade step %-14s mean lanes %.1f\n", sn[k], h[10] ? (double)h[18 + k] / (double)h[10] : 0.0);
@@ -1325,10 +1410,11 @@ int rt_primary_hits_device(rt_scene* s, const rt_render_desc* d, int32_t* tri_de
     int rc = check_desc(s, d, "rt_primary_hits");
     if (rc != RT_OK) return rc;
     if (!tri_dev || !dist_dev) return set_error(RT_ERR_INVALID_ARG, "rt_primary_hits: NULL output");
-    HIPCHK(hipSetDevice(s->device));
+    GUARD_DEVICE(s);
     RenderParams P;
-    int blocks;
-    rc = fill_params(s, d, &P, &blocks, false);
+    fill_params(s, d, &P);
+    const int blocks = ((d->width + 15) / 16) * ((d->height + 15) / 16);  // 256 threads per 16x16 tile
+    rc = grow_scene_spill(s, (size_t)blocks * kBlock, &P.spill, &P.spill_stride);
     if (rc != RT_OK) return rc;
     P.hit_tri = tri_dev, P.hit_dist = dist_dev;
     TimedLaunch tl;
@@ -1349,7 +1435,7 @@ int rt_primary_hits(rt_scene* s, const rt_render_desc* d, int32_t* tri_host, flo
     int rc = check_desc(s, d, "rt_primary_hits");
     if (rc != RT_OK) return rc;
     if (!tri_host || !dist_host) return set_error(RT_ERR_INVALID_ARG, "rt_primary_hits: NULL output");
-    HIPCHK(hipSetDevice(s->device));
+    GUARD_DEVICE(s);
     const size_t n = (size_t)d->width * d->height;
     int32_t* dt = nullptr;
     float* dd = nullptr;

@@ -110,7 +110,7 @@ def test_progressive_accumulation_continues_exactly(scene_small, hdr_pair):
 
 
 @pytest.mark.parametrize("launch_frames,unit_frames", [(2, 1), (3, 2), (64, 5)])
-def test_launch_and_unit_splits_do_not_change_the_image(scene_small, hdr_pair, monkeypatch, launch_frames, unit_frames):
+def test_launch_and_unit_splits_do_not_change_the_image(scene_small, hdr_pair, launch_frames, unit_frames):
     """The path loop hands (tile x unit_frames) units to persistent waves and folds each launch's samples in frame
     order; a long frame range is split into several launches.  However the range is cut, the image is the oracle's."""
     tris, nodes = scene_small
@@ -119,8 +119,9 @@ def test_launch_and_unit_splits_do_not_change_the_image(scene_small, hdr_pair, m
     eye, cam = rt.camera(-15.0, 12.0, 3.2)
     W, H, F = 75, 41, 7  # ragged tiles as well
     d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
-    monkeypatch.setenv("RT_AMD_CHUNK", str(launch_frames))
-    monkeypatch.setenv("RT_AMD_UNIT", str(unit_frames))
+    sc.set_tuning(launch_frames=launch_frames, unit_frames=unit_frames)  # rt_scene_set_tuning: per scene, through the ABI
+    t = sc.tuning()
+    assert (t.launch_frames, t.unit_frames) == (launch_frames, unit_frames)
     img = sc.render(d, 3, F)
     st = sc.render_stats(d, 3, F)
     ref, ost = O.render(tris, nodes, hdr, cache, W, H, 5, eye, cam, 3, F)

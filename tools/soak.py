@@ -18,11 +18,9 @@ while time.time() - t0 < budget:
     W, H = int(rng.randint(1, 700)), int(rng.randint(1, 400))
     F = int(rng.choice([1, 1, 2, 3, 7, 33, 70]))
     mode = int(rng.choice([3, 4, 5]))
-    os.environ["RT_AMD_CHUNK"] = str(int(rng.choice([1, 2, 5, 32, 64])))
-    os.environ["RT_AMD_UNIT"] = str(int(rng.choice([1, 2, 3, 8])))
-    os.environ["RT_AMD_REFILL"] = str(int(rng.choice([1, 16, 48, 64])))
-    os.environ["RT_AMD_LEAF"] = str(int(rng.choice([1, 8, 64])))
-    os.environ["RT_AMD_WAIT"] = str(int(rng.choice([1, 100, 4000, 10**8])))
+    sc.set_tuning(launch_frames=rng.choice([1, 2, 5, 32, 64]), unit_frames=rng.choice([1, 2, 3, 8]),
+                  shade_lanes=rng.choice([1, 16, 48, 64]), leaf_lanes=rng.choice([1, 8, 64]),
+                  wait_budget=rng.choice([1, 100, 4000, 10**8]))
     eye, cam = rt.camera(float(rng.uniform(0, 360)), float(rng.uniform(-89, 89)), float(rng.uniform(0.05, 8)))
     d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam, accumulate=int(rng.randint(2)))
     img = sc.render(d, int(rng.randint(0, 5000)), F)
