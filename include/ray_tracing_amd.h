@@ -161,6 +161,20 @@ int rt_primary_hits(rt_scene* s, const rt_render_desc* d, int32_t* tri_index_hos
 int rt_primary_hits_device(rt_scene* s, const rt_render_desc* d, int32_t* tri_index_dev, float* distance_dev,
                            void* hip_stream);
 
+/* rt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same arguments, same result (bit-identical to rt_render_device),
+ * but it calls no hipMalloc / hipFree / hipEventCreate or other allocating routine: the work-queue counters, the Sobol
+ * table, the stack spill of deep BVHs and the sample buffer come out of ONE static 64 MiB device array per GPU (held by
+ * every GPU the library runs on until the process ends; its address is looked up per device at rt_init /
+ * rt_scene_create).  Limits: 64 KiB header + stack spill (scenes deeper than 18 levels: 2 MiB per extra level) + one
+ * frame of samples (width*height*12 B) must fit, i.e. width*height <= 5 586 944 pixels on a shallow scene (1080p,
+ * 2560x1440 fit; 3840x2160 does not) -- larger requests return RT_ERR_INVALID_ARG and name the limit.  Frames per
+ * launch = what fits (<= rt_tuning.launch_frames), so large images run as more, shorter launches than rt_render_device.
+ * All calls on one GPU share that GPU's array (whatever the scene): calls that overlap on one GPU -- two streams, two
+ * threads -- race; serialise them.  Kernel timing (rt_kernel_time_ms) does not see these launches. */
+int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_dev,
+                             void* hip_stream);
+
 /* Scheduling knobs of the path loop, per scene (they change how the work is cut, never the image: tested).  Fields <= 0
  * select the default; rt_scene_set_tuning(s, NULL) restores all defaults.  No counterpart in the reference. */
 typedef struct rt_tuning {

@@ -123,6 +123,7 @@ _lib.rt_scene_destroy.argtypes = [C.c_void_p]
 _lib.rt_scene_destroy.restype = None
 _lib.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p]
 _lib.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+_lib.rt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 _lib.rt_scene_get_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
 _lib.rt_scene_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
 _lib.rt_primary_hits.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p]
@@ -302,6 +303,11 @@ class Scene:
         """Same on device memory (accum_ptr = device address of W*H*3 fp32), asynchronous on `stream`."""
         _check(_lib.rt_render_device(self._h, C.byref(desc), frame_begin, frame_count, C.c_void_p(accum_ptr),
                                      C.c_void_p(stream)))
+
+    def render_device_noalloc(self, desc: RenderDesc, frame_begin: int, frame_count: int, accum_ptr: int, stream: int = 0):
+        """render_device for callers that cannot allocate: workspace = the library's static per-GPU scratch array."""
+        _check(_lib.rt_render_device_noalloc(self._h, C.byref(desc), frame_begin, frame_count, C.c_void_p(accum_ptr),
+                                             C.c_void_p(stream)))
 
     def tuning(self) -> Tuning:
         t = Tuning()

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "rt_host.h"
@@ -920,6 +921,7 @@ static void remember_launch(const TimedLaunch& tl) {
     g_launches.push_back(tl);
 }
 static thread_local int g_device = -1;
+static int scratch_address(int device, unsigned char** out);
 
 // Makes the scene's device current for the duration of an entry point and restores the caller's afterwards.
 struct DeviceGuard {
@@ -982,7 +984,8 @@ int rt_init(int device) {
     if (device < 0 || device >= n) return set_error(RT_ERR_INVALID_ARG, "rt_init: device %d out of range (0..%d)", device, n - 1);
     HIPCHK(hipSetDevice(device));
     g_device = device;
-    return RT_OK;
+    unsigned char* p = nullptr;
+    return scratch_address(device, &p);  // this device's copy of the static scratch array (rt_render_device_noalloc)
 }
 
 void rt_scene_destroy(rt_scene* s) {
@@ -1164,7 +1167,7 @@ static int check_desc(const rt_scene* s, const rt_render_desc* d, const char* wh
 }
 
 // Device memory a launch needs beside the scene, the inputs and the outputs.  rt_render* takes it from buffers kept with
-// the scene (allocated / grown on demand).
+// the scene (allocated / grown on demand); rt_render_device_noalloc carves it out of the static scratch array.
 struct Workspace {
     unsigned* queue = nullptr;     // 8 work-queue counters, 64 B apart
     float2* sobol = nullptr;       // kMaxLaunchFrames x 4 Sobol pairs
@@ -1309,6 +1312,35 @@ static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count
     return RT_OK;
 }
 
+// ---- the static scratch array of rt_render_device_noalloc ---------------------------------------------------------------
+// One array per GPU (each device that loads this code object holds its own copy at its own address, until the process
+// ends).  Host code never uses the symbol's name as an address: the per-device address comes from hipGetSymbolAddress,
+// once per device, and is what kernels, memsets and copies receive.
+constexpr size_t kScratchBytes = (size_t)64 << 20;
+constexpr size_t kScratchQueueOff = 0;                                   // 8 counters, 64 B apart (512 B)
+constexpr size_t kScratchSobolOff = 4096;                                // kMaxLaunchFrames x 4 x float2 = 32 KiB
+constexpr size_t kScratchBodyOff = 65536;                                // stack spill (deep trees), then the sample buffer
+static_assert(kScratchSobolOff + (size_t)kMaxLaunchFrames * 4 * sizeof(float2) <= kScratchBodyOff, "scratch header layout");
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static unsigned char* g_scratch_ptr[kMaxDevices];  // per device: the address of ITS copy of `scratch`
+
+// `device` must be current.
+static int scratch_address(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return set_error(RT_ERR_INVALID_ARG, "device %d: the scratch table holds %d devices", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return set_error(RT_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
 }  // namespace rta
 
 extern "C" {
@@ -1344,6 +1376,41 @@ int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int 
     Workspace ws;
     rc = scene_workspace(s, d, frame_count, &ws);
     if (rc != RT_OK) return rc;
+    return launch_render<false>(s, d, frame_begin, frame_count, accum_dev, nullptr, (hipStream_t)stream, ws);
+}
+
+int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_dev, void* stream) {
+    int rc = check_render_args(s, d, frame_begin, frame_count, accum_dev);
+    if (rc != RT_OK) return rc;
+    if (frame_count == 0) return RT_OK;
+    GUARD_DEVICE(s);
+    unsigned char* base = nullptr;
+    rc = scratch_address(s->device, &base);  // looked up at rt_init / rt_scene_create; here only if neither ran on this device
+    if (rc != RT_OK) return rc;
+    Workspace ws;
+    ws.queue = (unsigned*)(base + kScratchQueueOff);
+    ws.sobol = (float2*)(base + kScratchSobolOff);
+    size_t off = kScratchBodyOff;
+    const size_t threads = (size_t)render_blocks(s) * kWave;
+    const size_t spill = spill_bytes_needed(s, threads);
+    if (spill > kScratchBytes - off)
+        return set_error(RT_ERR_INVALID_ARG, "rt_render_device_noalloc: a BVH of depth %d needs %zu bytes of stack spill; the static scratch holds %zu",
+                         s->max_stack - 1, spill, kScratchBytes - off);
+    if (spill) {
+        ws.spill = (int*)(base + off), ws.spill_stride = (long long)threads;
+        off += (spill + 255) & ~(size_t)255;
+    }
+    const size_t per_frame = (size_t)d->width * d->height * 3 * sizeof(float);
+    const size_t room = kScratchBytes > off ? kScratchBytes - off : 0;
+    if (per_frame > room)
+        return set_error(RT_ERR_INVALID_ARG, "rt_render_device_noalloc: one %dx%d frame of samples is %zu bytes; the static scratch has room for %zu (limit: width*height <= %zu pixels on this scene)",
+                         d->width, d->height, per_frame, room, room / (3 * sizeof(float)));
+    size_t lf = room / per_frame;
+    if (lf > (size_t)s->tuning.launch_frames) lf = (size_t)s->tuning.launch_frames;
+    if (lf > (size_t)frame_count) lf = (size_t)frame_count;
+    ws.samples = (float*)(base + off);
+    ws.launch_frames = (int)lf;
+    ws.timed = false;  // hipEventCreate allocates
     return launch_render<false>(s, d, frame_begin, frame_count, accum_dev, nullptr, (hipStream_t)stream, ws);
 }
 

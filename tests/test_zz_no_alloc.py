@@ -1,0 +1,93 @@
+"""-m gpu: rt_render_device_noalloc (static per-GPU scratch, no hipMalloc) against rt_render_device, through the C ABI.
+
+Collected last on purpose (test_zz_*): the round-end run is `pytest -x`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(t):
+    return np.ascontiguousarray(t.cpu().numpy(), np.float32).view(np.uint32)
+
+
+def _both(sc, desc, fb, fc, torch, dev):
+    """(rt_render_device image, rt_render_device_noalloc image) for the same frames, both starting from the same lastFrame."""
+    start = torch.rand((desc.height, desc.width, 3), dtype=torch.float32, device=dev)  # a non-trivial lastFrame to blend into
+    a, b = start.clone(), start.clone()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    sc.render_device(desc, fb, fc, a.data_ptr(), stream)
+    sc.render_device_noalloc(desc, fb, fc, b.data_ptr(), stream)
+    torch.cuda.synchronize(dev)
+    return a, b
+
+
+def test_noalloc_equals_render_device_two_calls_second_smaller(scene_small, hdr_pair):
+    import torch
+    dev = torch.device("cuda", 0)
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache, device=0)
+    eye, cam = rt.camera(20.0, 15.0, 3.5)
+    # first call: a large input (several launches: 40 frames > the 32 per launch); second: a smaller one on the same GPU's
+    # scratch, which still holds the first call's queue counters, Sobol pairs and samples
+    for (W, H, mode, fb, fc) in ((333, 187, 5, 3, 40), (61, 45, 5, 0, 3), (40, 24, 4, 7, 2)):
+        d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam)
+        a, b = _both(sc, d, fb, fc, torch, dev)
+        A, B = _bits(a), _bits(b)
+        nan = np.isnan(a.cpu().numpy()) & np.isnan(b.cpu().numpy())
+        assert ((A == B) | nan).all(), f"{W}x{H} mode {mode}: {int(((A != B) & ~nan).sum())} floats differ"
+        assert float(torch.nan_to_num(b).abs().sum()) > 0.0
+
+
+def test_noalloc_sum_mode_and_deep_tree_spill_from_scratch(hdr_pair):
+    """A 30-deep hand-built chain needs the global stack spill: the no-alloc entry carves it out of the scratch array."""
+    import torch
+    dev = torch.device("cuda", 0)
+    depth = 30
+    tris = np.zeros((depth + 1, 36), np.float32)
+    for k in range(depth + 1):
+        z = -1.0 + 0.01 * k
+        tris[k, :9] = np.array([[-0.5, -0.5, z], [0.5, -0.5, z], [0.0, 0.5, z]], np.float32).reshape(-1)
+        tris[k, 9:18] = np.tile([0, 0, 1], 3)
+        tris[k, 21:24] = 0.8
+        tris[k, 28] = 0.4
+        tris[k, 34] = 1.0
+
+    def box(lo, hi):
+        pts = tris[lo:hi, :9].reshape(-1, 3)
+        return pts.min(0), pts.max(0)
+
+    nodes = np.zeros((2 * depth + 2, 12), np.float32)
+    ids = [1 + 2 * i for i in range(depth)]
+    last_leaf = 1 + 2 * depth
+    for i in range(depth):
+        me, leaf = ids[i], ids[i] + 1
+        nxt = ids[i + 1] if i + 1 < depth else last_leaf
+        nodes[me, 0], nodes[me, 1] = nxt, leaf
+        nodes[me, 6:9], nodes[me, 9:12] = box(i, depth + 1)
+        nodes[leaf, 3], nodes[leaf, 4] = 1, i
+        nodes[leaf, 6:9], nodes[leaf, 9:12] = box(i, i + 1)
+    nodes[last_leaf, 3], nodes[last_leaf, 4] = 1, depth
+    nodes[last_leaf, 6:9], nodes[last_leaf, 9:12] = box(depth, depth + 1)
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache, device=0)
+    d = rt.make_desc(48, 40, mode=5, eye=(0.0, 0.0, 2.0), accumulate=rt.RT_ACCUM_SUM)
+    a, b = _both(sc, d, 0, 3, torch, dev)
+    assert np.array_equal(_bits(a), _bits(b))
+
+
+def test_noalloc_rejects_what_does_not_fit(scene_small, hdr_pair):
+    import torch
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache, device=0)
+    d = rt.make_desc(3840, 2160, mode=5)  # one frame of samples = 99.5 MB > the 64 MiB scratch
+    buf = torch.zeros((4,), dtype=torch.float32, device="cuda:0")  # never written: the call must fail before any launch
+    with pytest.raises(rt.RtError) as e:
+        sc.render_device_noalloc(d, 0, 1, buf.data_ptr(), 0)
+    assert e.value.code == -1 and "scratch" in str(e.value)
