@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "rt_host.h"
 
@@ -47,11 +48,16 @@ int rt_scene_cache_save(const char* path, uint64_t key, const float* tris, int n
     h.n_triangles = (uint64_t)n_triangles, h.n_nodes = (uint64_t)n_nodes;
     const size_t tb = (size_t)n_triangles * 36 * sizeof(float), nb = (size_t)n_nodes * 12 * sizeof(float);
     h.payload_hash = fnv1a64(nodes, nb, fnv1a64(tris, tb, 0xcbf29ce484222325ull));
-    // write beside the target and rename, so a reader never sees a half-written file
+    // write a uniquely named file beside the target and rename it, so a reader never sees a half-written file and ranks
+    // that hit a cold cache together (one process per GPU) do not write through each other
     char tmp[4096];
-    if (snprintf(tmp, sizeof(tmp), "%s.tmp", path) >= (int)sizeof(tmp)) return set_error(RT_ERR_INVALID_ARG, "rt_scene_cache_save: path too long");
-    FILE* f = fopen(tmp, "wb");
-    if (!f) return set_error(RT_ERR_IO, "rt_scene_cache_save: cannot open %s", tmp);
+    if (snprintf(tmp, sizeof(tmp), "%s.tmp.XXXXXX", path) >= (int)sizeof(tmp)) return set_error(RT_ERR_INVALID_ARG, "rt_scene_cache_save: path too long");
+    const int fd = mkstemp(tmp);
+    FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+    if (!f) {
+        if (fd >= 0) close(fd), remove(tmp);
+        return set_error(RT_ERR_IO, "rt_scene_cache_save: cannot create %s", tmp);
+    }
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
     ok = ok && (tb == 0 || fwrite(tris, 1, tb, f) == tb);
     ok = ok && (nb == 0 || fwrite(nodes, 1, nb, f) == nb);

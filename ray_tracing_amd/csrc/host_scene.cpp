@@ -406,7 +406,9 @@ static bool hdr_old_decrunch(RGBE4* scanline, int len, FILE* file, RGBE4* first)
         if (feof(file)) return false;
         if (scanline[0][0] == 1 && scanline[0][1] == 1 && scanline[0][2] == 1) {
             if (scanline == first) return false;  // repeat of a pixel before the scanline: malformed
-            for (int i = scanline[0][3] << rshift; i > 0 && len > 0; i--) {
+            if (rshift > 24) return false;        // a fifth consecutive repeat marker: the count would shift past an int
+            // (the count is formed in 64 bits: 255 << 24 does not fit a signed int)
+            for (long long i = (long long)scanline[0][3] << rshift; i > 0 && len > 0; i--) {
                 memcpy(&scanline[0][0], &scanline[-1][0], 4);
                 scanline++;
                 len--;

@@ -121,7 +121,10 @@ def cached_build(path: str, key: int, builder):
         return scene_cache_load(path, key)
     except RtError:
         tris, nodes = builder()
-        scene_cache_save(path, key, tris, nodes)
+        try:
+            scene_cache_save(path, key, tris, nodes)
+        except RtError:
+            pass  # a cache that cannot be written (read-only directory, another rank's race) is not fatal: the arrays are valid
         return tris, nodes
 
 

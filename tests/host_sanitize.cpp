@@ -115,6 +115,14 @@ int main(int argc, char** argv) {
         CHECK(rt_hdr_load(p.c_str(), &W, &H, &hdr) == RT_OK && W == 16 && H == 2);
         rt_free(hdr);
         f = fopen(p.c_str(), "wb");
+        // old RLE: one pixel, then six consecutive (1,1,1,n) repeat markers, some with a zero count: the shift of the
+        // repeat count must stay defined (UBSan) and the decode in bounds
+        const char c[] = "#?RADIANCE\nX\n\n-Y 2 +X 4\n\x10\x20\x30\x80\x01\x01\x01\x00\x01\x01\x01\x00\x01\x01\x01\x00\x01\x01\x01\x00\x01\x01\x01\xff\x01\x01\x01\xff";
+        fwrite(c, 1, sizeof(c) - 1, f);
+        fclose(f);
+        CHECK(rt_hdr_load(p.c_str(), &W, &H, &hdr) == RT_OK && W == 4 && H == 2);
+        rt_free(hdr);
+        f = fopen(p.c_str(), "wb");
         fputs("not an hdr file", f);
         fclose(f);
         CHECK(rt_hdr_load(p.c_str(), &W, &H, &hdr) != RT_OK);
