@@ -40,3 +40,11 @@ def scene_chap4():
 def scene_chap5():
     from ray_tracing_amd import scenes
     return scenes.chap5_scene()
+
+
+@pytest.fixture(scope="session")
+def scene_synth10m():
+    """BASELINE configs[4]: the ~10 M-triangle tessellated scene (256 objects x subdivision 100 + the floor slab =
+    10 240 012 triangles, ~3.6 M nodes, depth 27), built once per session with the product's bit-exact SAH builder."""
+    from ray_tracing_amd import scenes
+    return scenes.synthetic_scene(256, 100)

@@ -204,47 +204,35 @@ def test_bad_bvh_is_rejected(scene_small):
         rt.Scene(tris, bad)
 
 
-def test_deep_tree_spills_stack_exactly():
+def test_deep_tree_spills_stack_exactly(hdr_pair):
     """A hand-built left-deep chain whose deep subtree is always the nearer child makes the traversal stack grow to
-    60 entries, past the 32 kept in LDS, so the global spill path is exercised."""
+    60 entries, past the 18 kept in LDS, so the global spill path is exercised: primary query, chapter 4 and chapter 5
+    (render_kernel<5, *, SPILL>, statistics build included)."""
+    from scene_helpers import deep_chain
     depth = 60
-    tris = np.zeros((depth + 1, 36), np.float32)
-    for k in range(depth + 1):
-        z = -1.0 + 0.01 * k  # higher index = nearer to the eye at z = +2
-        tris[k, :9] = np.array([[-0.5, -0.5, z], [0.5, -0.5, z], [0.0, 0.5, z]], np.float32).reshape(-1)
-        tris[k, 9:18] = np.tile([0, 0, 1], 3)
-        tris[k, 21:24] = 1.0
-        tris[k, 34] = 1.0
-
-    def box(lo, hi):
-        pts = tris[lo:hi, :9].reshape(-1, 3)
-        return pts.min(0), pts.max(0)
-
-    nodes = np.zeros((2 * depth + 2, 12), np.float32)
-    ids = [1 + 2 * i for i in range(depth)]
-    last_leaf = 1 + 2 * depth
-    for i in range(depth):
-        me, leaf = ids[i], ids[i] + 1
-        nxt = ids[i + 1] if i + 1 < depth else last_leaf
-        nodes[me, 0], nodes[me, 1] = nxt, leaf
-        nodes[me, 6:9], nodes[me, 9:12] = box(i, depth + 1)
-        nodes[leaf, 3], nodes[leaf, 4] = 1, i
-        nodes[leaf, 6:9], nodes[leaf, 9:12] = box(i, i + 1)
-    nodes[last_leaf, 3], nodes[last_leaf, 4] = 1, depth
-    nodes[last_leaf, 6:9], nodes[last_leaf, 9:12] = box(depth, depth + 1)
+    tris, nodes = deep_chain(depth, base_color=0.8, roughness=0.3)
+    ident = np.eye(4, dtype=np.float32).reshape(16)
     sc = rt.Scene(tris, nodes)
     eye = np.array([0.0, 0.0, 2.0], np.float32)
     d = rt.make_desc(64, 32, eye=eye)
     tri, dist = sc.primary_hits(d)
-    otri, odist = O.primary_hits(tris, nodes, 64, 32, eye, np.eye(4, dtype=np.float32).reshape(16))
+    otri, odist = O.primary_hits(tris, nodes, 64, 32, eye, ident)
     assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
     assert (tri == depth).any()
     hdr = np.full((4, 8, 3), 0.5, np.float32)
     sc2 = rt.Scene(tris, nodes, hdr, None)
     d4 = rt.make_desc(32, 32, mode=4, eye=eye)
     img = sc2.render(d4, 0, 2)
-    ref, _ = O.render(tris, nodes, hdr, None, 32, 32, 4, eye, np.eye(4, dtype=np.float32).reshape(16), 0, 2)
-    _assert_images_equal(img, ref, "deep tree render")
+    ref, _ = O.render(tris, nodes, hdr, None, 32, 32, 4, eye, ident, 0, 2)
+    _assert_images_equal(img, ref, "deep tree render, mode 4")
+    hdr5, cache5 = hdr_pair
+    sc5 = rt.Scene(tris, nodes, hdr5, cache5)
+    for (W, H, F, e) in ((48, 40, 3, eye), (33, 21, 2, np.array([0.3, 0.1, 0.9], np.float32))):
+        d5 = rt.make_desc(W, H, mode=5, eye=e)
+        img = sc5.render(d5, 1, F)
+        ref, ost = O.render(tris, nodes, hdr5, cache5, W, H, 5, e, ident, 1, F)
+        _assert_images_equal(img, ref, "deep tree render, mode 5")
+        assert sc5.render_stats(d5, 1, F) == ost
 
 
 def test_mode5_rejects_more_bounces_than_the_sobol_table_holds(scene_small, hdr_pair):
@@ -499,3 +487,77 @@ def test_scene_without_environment_map(scene_small):
         assert sc.render_stats(d, 0, F) == ost
     with pytest.raises(rt.RtError):
         sc.render(rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam), 0, 1)
+
+
+def test_oversize_image_is_refused(scene_small):
+    """A pixel travels through the path loop as (x | y << 16): widths over 65535 and heights over 32767 are refused before any
+    launch (RT_ERR_INVALID_ARG), by every entry point that takes a descriptor."""
+    tris, nodes = scene_small
+    sc = rt.Scene(tris, nodes)
+    for (W, H) in ((65537, 1), (8, 40000), (0, 5), (5, -1)):
+        d = rt.make_desc(4, 4, mode=4)
+        d.width, d.height = W, H
+        buf = np.zeros(16, np.float32)  # never touched
+        with pytest.raises(rt.RtError) as e:
+            rt._check(rt.lib().rt_render(sc._h, d, 0, 1, buf.ctypes.data))
+        assert e.value.code == -1
+        with pytest.raises(rt.RtError):
+            rt._check(rt.lib().rt_primary_hits(sc._h, d, buf.ctypes.data, buf.ctypes.data))
+    d = rt.make_desc(65535, 1, mode=4, eye=(0, 0.5, 3))  # the widest image that is accepted
+    assert sc.render(d, 0, 1).shape == (1, 65535, 3)
+
+
+# ---- BASELINE config "synthetic": ~10 M triangles, 4K ---------------------------------------------------------------------
+
+def test_synthetic_10m_window_bit_exact_with_stats(scene_synth10m, hdr_pair):
+    """The real 10 240 012-triangle scene (depth 27 > the 18 stack entries kept in LDS => render_kernel<5, *, SPILL>, the
+    waiting-budget rule of the scheduler on traversals of ~1600 nodes): a 320x180 window, 2 frames, camera inside the object
+    grid — image and traversal statistics equal the oracle's; primary hits (chapter-2 rule) too."""
+    tris, nodes = scene_synth10m
+    assert tris.shape[0] == 10240012
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(15.0, 25.0, 6.0)
+    W, H, F = 320, 180, 2
+    d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+    img = sc.render(d, 0, F)
+    ref, ost = O.render(tris, nodes, hdr, cache, W, H, 5, eye, cam, 0, F)
+    _assert_images_equal(img, ref, "synthetic 10M window")
+    st = sc.render_stats(d, 0, F)
+    assert st == ost, (st, ost)
+    assert ost["internal_nodes"] / ost["rays"] > 300
+    tri, dist = sc.primary_hits(rt.make_desc(W, H, eye=eye, camera_rotate=cam))
+    otri, odist = O.primary_hits(tris, nodes, W, H, eye, cam)
+    assert (tri >= 0).mean() > 0.5
+    assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
+
+
+def test_synthetic_10m_full_4k_properties(scene_synth10m, hdr_pair):
+    """The same scene at the config's full 3840x2160 through size-independent properties: one call == two calls cut at an odd
+    frame (bit-exact), sum-mode buffer / N == running mean (fp32 summation order), and the 320x180 oracle-checked window's
+    statistics are those of the same camera (downsampled image agrees statistically)."""
+    tris, nodes = scene_synth10m
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(15.0, 25.0, 6.0)
+    W, H, F = 3840, 2160, 3
+    d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+    one = sc.render(d, 0, F)
+    two = sc.render(d, 0, 1)
+    two = sc.render(d, 1, F - 1, two)
+    _assert_images_equal(one, two, "synthetic 4K, one call vs two")
+    ds = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam, accumulate=rt.RT_ACCUM_SUM)
+    s = sc.render(ds, 0, F)
+    ok = np.isfinite(one) & np.isfinite(s)
+    assert ok.mean() > 0.999
+    assert np.allclose(s[ok] / F, one[ok], rtol=1e-4, atol=1e-5)
+    # same camera, 12x fewer pixels per side: box-filtered 4K image vs the small render (both 3 spp per pixel; the small one is
+    # the configuration test_synthetic_10m_window_bit_exact_with_stats checks against the oracle)
+    small = sc.render(rt.make_desc(320, 180, mode=5, eye=eye, camera_rotate=cam), 0, F)
+    a = rt.tonemap_rgb8(one).astype(np.float64) / 255.0
+    b = rt.tonemap_rgb8(small).astype(np.float64) / 255.0
+    A = a.reshape(180, 12, 320, 12, 3).mean((1, 3))
+    B = b
+    A8, B8 = (x.reshape(45, 4, 80, 4, 3).mean((1, 3)) for x in (A, B))
+    assert np.sqrt(np.mean((A8 - B8) ** 2)) <= 0.05
+    assert abs(A.mean() - B.mean()) <= 0.03 * A.mean()

@@ -48,32 +48,8 @@ def test_noalloc_sum_mode_and_deep_tree_spill_from_scratch(hdr_pair):
     """A 30-deep hand-built chain needs the global stack spill: the no-alloc entry carves it out of the scratch array."""
     import torch
     dev = torch.device("cuda", 0)
-    depth = 30
-    tris = np.zeros((depth + 1, 36), np.float32)
-    for k in range(depth + 1):
-        z = -1.0 + 0.01 * k
-        tris[k, :9] = np.array([[-0.5, -0.5, z], [0.5, -0.5, z], [0.0, 0.5, z]], np.float32).reshape(-1)
-        tris[k, 9:18] = np.tile([0, 0, 1], 3)
-        tris[k, 21:24] = 0.8
-        tris[k, 28] = 0.4
-        tris[k, 34] = 1.0
-
-    def box(lo, hi):
-        pts = tris[lo:hi, :9].reshape(-1, 3)
-        return pts.min(0), pts.max(0)
-
-    nodes = np.zeros((2 * depth + 2, 12), np.float32)
-    ids = [1 + 2 * i for i in range(depth)]
-    last_leaf = 1 + 2 * depth
-    for i in range(depth):
-        me, leaf = ids[i], ids[i] + 1
-        nxt = ids[i + 1] if i + 1 < depth else last_leaf
-        nodes[me, 0], nodes[me, 1] = nxt, leaf
-        nodes[me, 6:9], nodes[me, 9:12] = box(i, depth + 1)
-        nodes[leaf, 3], nodes[leaf, 4] = 1, i
-        nodes[leaf, 6:9], nodes[leaf, 9:12] = box(i, i + 1)
-    nodes[last_leaf, 3], nodes[last_leaf, 4] = 1, depth
-    nodes[last_leaf, 6:9], nodes[last_leaf, 9:12] = box(depth, depth + 1)
+    from scene_helpers import deep_chain
+    tris, nodes = deep_chain(30, base_color=0.8, roughness=0.4)
     hdr, cache = hdr_pair
     sc = rt.Scene(tris, nodes, hdr, cache, device=0)
     d = rt.make_desc(48, 40, mode=5, eye=(0.0, 0.0, 2.0), accumulate=rt.RT_ACCUM_SUM)
