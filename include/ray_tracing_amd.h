@@ -183,9 +183,25 @@ typedef struct rt_tuning {
     int32_t leaf_lanes;        /* lanes holding a leaf that trigger a cooperative leaf pass; default 8 */
     int32_t shade_lanes;       /* lanes waiting for the shade pass that trigger it; default 48 */
     int32_t wait_budget;       /* lane-passes spent waiting that trigger the shade pass; default 4000 */
+    int32_t no_cull;           /* > 0: walk every node whose box the ray hits, as the reference does (f5:295-307), instead
+                                  of skipping subtrees that provably cannot hold a closer hit; default 0 (skip them) */
 } rt_tuning;
 int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out);
 int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t);
+
+/* What rt_scene_create found.  cull_enabled = 0 when the BVH does not allow closest-hit culling (a box that does not
+ * contain its children's boxes or its triangles, a non-finite box) or rt_tuning.no_cull is set: results are the same
+ * either way, only the number of nodes visited differs.  No counterpart in the reference. */
+typedef struct rt_scene_info {
+    int32_t n_triangles, n_nodes;
+    int32_t bvh_depth;         /* levels below the root */
+    int32_t stack_spill;       /* 1: deeper than the 18 stack entries kept in LDS (global spill in use) */
+    int32_t cull_enabled;
+    float cull_eps;            /* scene part of a ray's culling margin: 2^-13 * scene extent (each box adds the shape
+                                  term of the worst triangle below it: 2^-14 * longest edge / sin(min angle / 2)) */
+    int32_t device;
+} rt_scene_info;
+int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
 
 /* Traversal statistics of a render (same rays as rt_render): totals over all hitBVH invocations. */
 typedef struct rt_trace_stats {
@@ -197,6 +213,11 @@ typedef struct rt_trace_stats {
     uint64_t hit_updates;      /* closest-hit improvements inside hitArray (H), f5:250-253 */
 } rt_trace_stats;
 int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out);
+/* Same counters for the walk the product kernels EXECUTE on these rays: subtrees that provably hold no closer hit are
+ * skipped (unless rt_tuning.no_cull) and environment-visibility rays stop at their first hit (only isHit is used,
+ * f5:869).  rays and paths equal rt_render_stats'; the other counters are <= it.  This is the work the timed kernel
+ * does (bench.py's roofline numerator); rt_render_stats is the reference's algorithmic count. */
+int rt_render_stats_executed(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out);
 
 /* Average duration (ms) of the path-loop kernel launches made by the calling thread since the last call with
  * reset != 0, measured with HIP events on the launch stream; *launches receives the count. */

@@ -91,7 +91,13 @@ class TraceStats(C.Structure):
 
 class Tuning(C.Structure):
     """rt_tuning: scheduling knobs of the path loop (they never change the image)."""
-    _fields_ = [(n, C.c_int32) for n in ("launch_frames", "unit_frames", "leaf_lanes", "shade_lanes", "wait_budget")]
+    _fields_ = [(n, C.c_int32) for n in ("launch_frames", "unit_frames", "leaf_lanes", "shade_lanes", "wait_budget", "no_cull")]
+
+
+class SceneInfo(C.Structure):
+    """rt_scene_info."""
+    _fields_ = [("n_triangles", C.c_int32), ("n_nodes", C.c_int32), ("bvh_depth", C.c_int32), ("stack_spill", C.c_int32),
+                ("cull_enabled", C.c_int32), ("cull_eps", C.c_float), ("device", C.c_int32)]
 
 
 class RtError(RuntimeError):
@@ -126,9 +132,11 @@ _lib.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.
 _lib.rt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 _lib.rt_scene_get_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
 _lib.rt_scene_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+_lib.rt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
 _lib.rt_primary_hits.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p]
 _lib.rt_primary_hits_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
+_lib.rt_render_stats_executed.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
 _lib.rt_kernel_time_ms.argtypes = [_f32p, C.POINTER(C.c_int), C.c_int]
 _lib.rt_hash_fnv1a64.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
 _lib.rt_hash_fnv1a64.restype = C.c_uint64
@@ -309,6 +317,11 @@ class Scene:
         _check(_lib.rt_render_device_noalloc(self._h, C.byref(desc), frame_begin, frame_count, C.c_void_p(accum_ptr),
                                              C.c_void_p(stream)))
 
+    def info(self) -> SceneInfo:
+        i = SceneInfo()
+        _check(_lib.rt_scene_get_info(self._h, C.byref(i)))
+        return i
+
     def tuning(self) -> Tuning:
         t = Tuning()
         _check(_lib.rt_scene_get_tuning(self._h, C.byref(t)))
@@ -335,9 +348,11 @@ class Scene:
         _check(_lib.rt_primary_hits_device(self._h, C.byref(desc), C.c_void_p(tri_ptr), C.c_void_p(dist_ptr),
                                            C.c_void_p(stream)))
 
-    def render_stats(self, desc: RenderDesc, frame_begin: int, frame_count: int) -> dict:
+    def render_stats(self, desc: RenderDesc, frame_begin: int, frame_count: int, executed: bool = False) -> dict:
+        """Traversal counters of the reference's walk (default) or of the walk the product kernel executes."""
         st = TraceStats()
-        _check(_lib.rt_render_stats(self._h, C.byref(desc), frame_begin, frame_count, C.byref(st)))
+        fn = _lib.rt_render_stats_executed if executed else _lib.rt_render_stats
+        _check(fn(self._h, C.byref(desc), frame_begin, frame_count, C.byref(st)))
         return st.as_dict()
 
 

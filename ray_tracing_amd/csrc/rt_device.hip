@@ -22,6 +22,7 @@
 
 #include "rt_host.h"
 #include "rt_shade.h"
+#include "rt_trav.h"
 
 namespace rta {
 
@@ -62,7 +63,7 @@ __device__ unsigned long long g_opcycles[8];
 struct DevScene {
     const float4* ttri;   // 3 x float4 per triangle: (p1.xyz,p2.x) (p2.yz,p3.xy) (p3.z,N.xyz)
     const float* tris;    // Triangle_encoded[nT], the caller's layout
-    const float4* nodes;  // 4 x float4 per internal node: (lAA,lBB.x) (lBB.yz,rAA.xy) (rAA.z,rBB) (lentry,rentry,-,-)
+    const float4* nodes;  // 4 x float4 per internal node: (lAA,lBB.x) (lBB.yz,rAA.xy) (rAA.z,rBB) (lentry,rentry,lmargin,rmargin)
     const float4* dmat;   // 4 x float4 per triangle: material-only terms of chapter 5's BRDF (MatPre), see rt_shade.h
     const float4* hdr;    // hdrMap as RGBX
     const float4* cache;  // hdrCache as RGBX
@@ -70,6 +71,8 @@ struct DevScene {
     int hdrW, hdrH;
     int root_entry;       // packed entry of node 1
     int has_root;
+    float cull_eps;       // scene part of a ray's culling margin (see hitAABB_cull); +inf = this scene is never culled
+    float cull_geo_max;   // largest finite per-box margin of the node records
 };
 
 // packed stack entry: >= 0 internal record index; < 0 leaf: bit31 | (n-1) << 24 | first triangle index
@@ -93,44 +96,14 @@ struct RenderParams {
     int* spill;            // global stack spill, [depth - kLdsDepth][thread]
     long long spill_stride;
     unsigned long long* stats;  // 6 counters (STATS builds)
+    int stats_executed;    // STATS builds: 0 = count the reference's walk (no culling, env-visibility rays walked fully);
+                           // 1 = count what the product kernel executes (culling, env-visibility rays stop at the first hit)
     int refill;            // lanes waiting for a handler that trigger a handler pass
     int leaf_lanes;        // lanes holding a leaf that trigger a cooperative leaf pass
     int wait_budget;       // lane-passes spent waiting for the shade pass that trigger it
     int32_t* hit_tri;      // primary-hit query outputs
     float* hit_dist;
 };
-
-// ---- T2: hitAABB, f5:225-238 ------------------------------------------------------------------------------------
-__device__ __forceinline__ float hitAABB(vec3 S, vec3 invdir, vec3 AA, vec3 BB) {
-    const vec3 f = (BB - S) * invdir;
-    const vec3 n = (AA - S) * invdir;
-    const vec3 tmax = max3(f, n);
-    const vec3 tmin = min3(f, n);
-    const float t1 = fmin_(tmax.x, fmin_(tmax.y, tmax.z));
-    const float t0 = fmax_(tmin.x, fmax_(tmin.y, tmin.z));
-    return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
-}
-
-// ---- T1: hitTriangle (distance part), f5:168-209.  N0 = precomputed normalize(cross(p2-p1, p3-p1)). -------------
-__device__ __forceinline__ bool hitTriangleT(vec3 p1, vec3 p2, vec3 p3, vec3 N0, vec3 S, vec3 d, float* t_out) {
-    // The reference flips N to face the ray first (f5:183-186).  Every later use is odd in N (|dot(N,d)|, the quotient
-    // of two dot products with N, the signs of a,b,c tested for "all > 0 or all < 0"), and fp32 negation commutes with
-    // round-to-nearest products and sums, so the unflipped normal gives bit-identical t and the same accept/reject.
-    const vec3 N = N0;
-    if (fabs_(dot(N, d)) < 0.00001f) return false;
-    const float t = (dot(N, p1) - dot(S, N)) / dot(d, N);
-    if (t < 0.0005f) return false;
-    const vec3 P = S + d * t;
-    const vec3 c1 = cross(p2 - p1, P - p1);
-    const vec3 c2 = cross(p3 - p2, P - p2);
-    const vec3 c3 = cross(p1 - p3, P - p3);
-    const float a = dot(c1, N), b = dot(c2, N), c = dot(c3, N);
-    const bool r1 = (a > 0.0f && b > 0.0f && c > 0.0f);
-    const bool r2 = (a < 0.0f && b < 0.0f && c < 0.0f);
-    if (!(r1 || r2)) return false;
-    *t_out = t;
-    return true;
-}
 
 struct LaneStack {
     int* lds;              // &s_stack[threadIdx.x]; entry k at lds[k * kBlock]
@@ -157,6 +130,7 @@ enum TieRule { TIE_SHADER = 0, TIE_CHAP2 = 1 };
 // Returns the closest triangle index (-1 = miss) and its distance.  ANYHIT returns at the first accepted hit.
 template <bool ANYHIT, int TIE, bool STATS, bool SPILL>
 __device__ __forceinline__ int hitBVH(const DevScene& sc, const LaneStack& stk, vec3 S, vec3 d, float* dist, Stats& st) {
+    constexpr bool CULL = !STATS && !ANYHIT;  // statistics builds walk exactly the reference's nodes
     float best = INF_;
     int best_tri = -1;
     int best_first = -1;
@@ -166,6 +140,8 @@ __device__ __forceinline__ int hitBVH(const DevScene& sc, const LaneStack& stk, 
         return -1;
     }
     const vec3 invdir = v3(1.0f) / d;
+    const bool slow = !(finite3(invdir) && finite3(S));
+    const float ceps = CULL ? cull_margin(sc.cull_eps, sc.cull_geo_max, S, invdir, slow) : 0.0f;
     int sp = 0;
     int cur = sc.root_entry;
     while (true) {
@@ -173,8 +149,20 @@ __device__ __forceinline__ int hitBVH(const DevScene& sc, const LaneStack& stk, 
             if (STATS) st.internal++;
             const float4 q0 = sc.nodes[cur * 4 + 0], q1 = sc.nodes[cur * 4 + 1], q2 = sc.nodes[cur * 4 + 2],
                          q3 = sc.nodes[cur * 4 + 3];
-            const float d1 = hitAABB(S, invdir, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y));
-            const float d2 = hitAABB(S, invdir, v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w));
+            const vec3 lAA = v3(q0.x, q0.y, q0.z), lBB = v3(q0.w, q1.x, q1.y);
+            const vec3 rAA = v3(q1.z, q1.w, q2.x), rBB = v3(q2.y, q2.z, q2.w);
+            float d1, d2;
+            if (CULL && !slow) {
+                float c1, c2;
+                d1 = hitAABB_cull(S, invdir, lAA, lBB, ceps, q3.z, &c1);
+                d2 = hitAABB_cull(S, invdir, rAA, rBB, ceps, q3.w, &c2);
+                // chapter 2 also accepts t == best from a leaf further right (c2:512): still t <= best < t0c
+                if (c1 > best) d1 = -1.0f;
+                if (c2 > best) d2 = -1.0f;
+            } else {
+                d1 = hitAABB(S, invdir, lAA, lBB);
+                d2 = hitAABB(S, invdir, rAA, rBB);
+            }
             const int le = __float_as_int(q3.x), re = __float_as_int(q3.y);
             if (d1 > 0.0f && d2 > 0.0f) {
                 if (d1 < d2) {  // left first
@@ -361,21 +349,6 @@ enum RayKind { K_PRIMARY = 0, K_SHADOW = 1, K_BOUNCE = 2, K_NONE = 3 };
 constexpr int kWaitBudget = 4000;  // lane-passes; of the order of (VALU cost of a shade pass) / (one lane's share of a traversal pass)
 constexpr int kHandlerLanes = 48;  // run a handler once this many lanes wait for it (or nothing is traversing)
 
-// hitAABB (f5:225-238) with hardware min/max.  Equal to the ternary form whenever no operand is NaN (the results are
-// only compared, so the sign of a zero does not matter); rays that can produce NaN (a zero/NaN direction component or a
-// non-finite origin) take the exact form instead (`slow`).
-__device__ __forceinline__ float hitAABB_fast(vec3 S, vec3 invdir, vec3 AA, vec3 BB) {
-    const vec3 f = (BB - S) * invdir;
-    const vec3 n = (AA - S) * invdir;
-    const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fmaxf(f.y, n.y)), __builtin_fmaxf(f.z, n.z));
-    const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(f.x, n.x), __builtin_fminf(f.y, n.y)), __builtin_fminf(f.z, n.z));
-    return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
-}
-__device__ __forceinline__ bool finite3(vec3 v) {
-    const float inf = __builtin_inff();
-    return (fabs_(v.x) < inf) && (fabs_(v.y) < inf) && (fabs_(v.z) < inf);
-}
-
 constexpr int kWave = 64;         // render_kernel: one wave64 per workgroup; work units are 8x8 pixel tiles x kUnitFrames frames
 constexpr int kMaxLaunchFrames = 1024;  // bound of RT_AMD_CHUNK (sizes the per-launch Sobol table)
 constexpr int kLaunchFrames = 32;  // frames per kernel launch (sample buffer = W x H x frames x 12 B)
@@ -440,6 +413,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     int bounce = 0;
     vec3 S = v3(0), d = v3(0, 0, 1), invdir = v3(0);  // ray in flight
     bool slow = false;              // this ray needs the NaN-exact box test
+    // statistics builds walk exactly the reference's nodes (algorithmic counts) unless asked for the executed walk
+    const bool CULL = !STATS || P.stats_executed != 0;
+    float ceps = __builtin_inff();  // culling margin of the ray in flight (hitAABB_cull); +inf = never cull
     int cur = 0, sp = 0, best_tri = -1, ti = 0;        // ti: next triangle of the leaf in `cur`
     float best = INF_;
     float leaf_best = INF_;         // STATS only
@@ -686,6 +662,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 best = INF_, best_tri = -1, sp = 0, cur = sc.root_entry;
                 invdir = v3(1.0f) / d;
                 slow = !(finite3(invdir) && finite3(S));
+                ceps = CULL ? cull_margin(sc.cull_eps, sc.cull_geo_max, S, invdir, slow) : __builtin_inff();
                 s_ray[2 * lane] = make_float4(S.x, S.y, S.z, d.x);  // for the cooperative leaf pass
                 s_ray[2 * lane + 1] = make_float4(d.y, d.z, 0.0f, 0.0f);
                 if (!sc.has_root) {
@@ -702,11 +679,16 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (op == OP_INT) {
                 if (STATS) st.internal++;
                 const float4 q0 = sc.nodes[cur * 4 + 0], q1 = sc.nodes[cur * 4 + 1], q2 = sc.nodes[cur * 4 + 2];
-                const float2 q3 = *reinterpret_cast<const float2*>(&sc.nodes[cur * 4 + 3]);  // the two child entries
+                const float4 q3 = sc.nodes[cur * 4 + 3];  // the two child entries, the two children's culling margins
                 const vec3 lAA = v3(q0.x, q0.y, q0.z), lBB = v3(q0.w, q1.x, q1.y);
                 const vec3 rAA = v3(q1.z, q1.w, q2.x), rBB = v3(q2.y, q2.z, q2.w);
-                float d1 = hitAABB_fast(S, invdir, lAA, lBB);
-                float d2 = hitAABB_fast(S, invdir, rAA, rBB);
+                // a child whose inflated box starts beyond the closest hit so far cannot change the result: skip it
+                // (ceps = +inf for rays that must not be culled: then c1 = c2 = -inf)
+                float c1, c2;
+                float d1 = hitAABB_cull(S, invdir, lAA, lBB, ceps, q3.z, &c1);
+                float d2 = hitAABB_cull(S, invdir, rAA, rBB, ceps, q3.w, &c2);
+                if (c1 > best) d1 = -1.0f;
+                if (c2 > best) d2 = -1.0f;
                 if (slow) {
                     d1 = hitAABB(S, invdir, lAA, lBB);
                     d2 = hitAABB(S, invdir, rAA, rBB);
@@ -788,7 +770,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                         best = t;
                         best_tri = (int)(unsigned)key;
                         // an env-visibility ray only needs isHit (f5:869); statistics builds count the full walk
-                        if (!STATS && kind == K_SHADOW) done = true;
+                        if (CULL && kind == K_SHADOW) done = true;
                     }
                 }
                 ti += serve;
@@ -965,7 +947,8 @@ struct rt_scene {
     float* d_frame = nullptr;    // rt_render: device copy of the caller's host accumulation buffer
     size_t frame_bytes = 0;
     int cu_count = 0;
-    rt_tuning tuning{kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget};
+    rt_tuning tuning{kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0};
+    float cull_eps = 0.0f;       // scene part of the culling margin; +inf = the BVH / triangles do not allow culling
 };
 
 static int f2i_checked(float f, int* out) {
@@ -1092,8 +1075,85 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
         q[12] = p.p_d, q[13] = p.p_s, q[14] = p.p_c, q[15] = p.g1_lg;
     }
 
+    // ---- culling margins (hitAABB_cull) ------------------------------------------------------------------------------
+    // Culling needs nested boxes.  A ray's margin scales with the scene extent; each box adds the shape term of the worst
+    // triangle below it: 2^-14 * longest edge / sin(smallest angle / 2) (the point S + d*t that hitTriangle accepts can lie
+    // that far beyond the tip of a needle-shaped triangle), kept per child in the node record.
+    // "Acceptable" triangles are those hitTriangle can ever accept (finite vertices, finite non-zero plane normal); the
+    // others never produce a hit and are ignored here.
+    double cull_extent = 0.0;
+    float cull_geo_max = 0.0f;
+    bool cull_ok = has_root;
+    {
+        const float inf = __builtin_inff();
+        auto fin = [inf](float v) { return fabsf(v) < inf; };
+        std::vector<float> tri_margin(nT > 0 ? nT : 0, -1.0f);  // -1: not acceptable
+        for (int i = 0; i < nT; ++i) {
+            const float* q = &ttri[(size_t)i * 12];
+            bool ok = true;
+            for (int k = 0; k < 12; ++k) ok = ok && fin(q[k]);
+            ok = ok && (q[9] != 0.0f || q[10] != 0.0f || q[11] != 0.0f);
+            if (!ok) continue;
+            for (int k = 0; k < 9; ++k)
+                if (fabs((double)q[k]) > cull_extent) cull_extent = fabs((double)q[k]);
+            tri_margin[i] = tri_cull_margin(q);
+        }
+        // per node: the largest triangle margin below it (children come after their parent in `order`: walk it backwards)
+        std::vector<float> node_margin(nN > 0 ? nN : 0, 0.0f);
+        auto leaf_margin = [&](const NodeRec& cn) {
+            float m = 0.0f;
+            const int first = (int)cn.index, cnt = (int)cn.n;
+            for (int i = first; i < first + cnt; ++i)
+                if (tri_margin[i] > m) m = tri_margin[i];
+            return m;
+        };
+        for (size_t k = order.size(); k-- > 0;) {
+            const NodeRec& nd = N[order[k]];
+            const int ch[2] = {(int)nd.left, (int)nd.right};
+            float m = 0.0f;
+            for (int c = 0; c < 2; ++c) {
+                const NodeRec& cn = N[ch[c]];
+                if (cn.n > 0.0f) node_margin[ch[c]] = leaf_margin(cn);
+                if (node_margin[ch[c]] > m) m = node_margin[ch[c]];
+                memcpy(&rec[k * 16 + 14 + c], &node_margin[ch[c]], 4);
+                if (node_margin[ch[c]] < inf && node_margin[ch[c]] > cull_geo_max) cull_geo_max = node_margin[ch[c]];
+            }
+            node_margin[order[k]] = m;
+        }
+        // every box the traversal tests (all nodes but the root) must contain its children's boxes / its triangles
+        for (size_t k = 0; k < order.size() && cull_ok; ++k) {
+            const NodeRec& nd = N[order[k]];
+            const int ch[2] = {(int)nd.left, (int)nd.right};
+            for (int c = 0; c < 2 && cull_ok; ++c) {
+                const NodeRec& cn = N[ch[c]];
+                const float bb[6] = {cn.AA.x, cn.AA.y, cn.AA.z, cn.BB.x, cn.BB.y, cn.BB.z};
+                for (int j = 0; j < 6; ++j) {
+                    cull_ok = cull_ok && fin(bb[j]);
+                    if (fabs((double)bb[j]) > cull_extent) cull_extent = fabs((double)bb[j]);
+                }
+                if (order[k] != 1)  // (the root's own box is never tested, f5:268-291)
+                    cull_ok = cull_ok && cn.AA.x >= nd.AA.x && cn.AA.y >= nd.AA.y && cn.AA.z >= nd.AA.z && cn.BB.x <= nd.BB.x &&
+                              cn.BB.y <= nd.BB.y && cn.BB.z <= nd.BB.z;
+                if (cn.n > 0.0f) {  // leaf: its acceptable triangles lie inside its box
+                    const int first = (int)cn.index, cnt = (int)cn.n;
+                    for (int i = first; i < first + cnt && cull_ok; ++i) {
+                        if (tri_margin[i] < 0.0f) continue;
+                        const float* q = &ttri[(size_t)i * 12];
+                        for (int v = 0; v < 3; ++v)
+                            cull_ok = cull_ok && q[v * 3] >= cn.AA.x && q[v * 3] <= cn.BB.x && q[v * 3 + 1] >= cn.AA.y &&
+                                      q[v * 3 + 1] <= cn.BB.y && q[v * 3 + 2] >= cn.AA.z && q[v * 3 + 2] <= cn.BB.z;
+                    }
+                }
+            }
+        }
+    }
+    float cull_eps = __builtin_inff();
+    if (cull_ok && cull_extent > 1e-10 && cull_extent < 1e30) cull_eps = nextafterf((float)(cull_extent / 8192.0), __builtin_inff());  // 2^-13 * extent
+
     rt_scene* s = new rt_scene();
     s->device = g_device;
+    s->cull_eps = cull_eps;
+    s->dev.cull_geo_max = cull_geo_max;
     s->nT = nT, s->nN = nN, s->max_stack = need_stack;
     auto fail = [&](int rc) {
         rt_scene_destroy(s);
@@ -1150,6 +1210,7 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     s->dev.hdrW = hdrW, s->dev.hdrH = hdrH;
     s->dev.has_root = has_root ? 1 : 0;
     s->dev.root_entry = has_root ? entry[1] : 0;
+    s->dev.cull_eps = cull_eps;
     *out = s;
     return RT_OK;
 }
@@ -1233,9 +1294,10 @@ static int check_render_args(const rt_scene* s, const rt_render_desc* d, int fra
 // Allocates nothing unless ws.timed (HIP events).
 template <bool STATS>
 static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_dev,
-                         unsigned long long* stats_dev, hipStream_t stream, const Workspace& ws) {
+                         unsigned long long* stats_dev, hipStream_t stream, const Workspace& ws, int stats_executed = 0) {
     RenderParams P;
     fill_params(s, d, &P);
+    P.stats_executed = stats_executed;
     P.max_bounce = d->max_bounce > 0 ? d->max_bounce : (d->mode == RT_MODE_CHAP5 ? 4 : 6);
     P.accum = accum_dev;
     P.stats = stats_dev;
@@ -1353,7 +1415,7 @@ int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out) {
 
 int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     if (!s) return set_error(RT_ERR_INVALID_ARG, "rt_scene_set_tuning: NULL scene");
-    const rt_tuning def = {kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget};
+    const rt_tuning def = {kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0};
     rt_tuning n = t ? *t : def;
     if (n.launch_frames <= 0) n.launch_frames = def.launch_frames;
     if (n.unit_frames <= 0) n.unit_frames = def.unit_frames;
@@ -1364,7 +1426,20 @@ int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     if (n.unit_frames > kMaxLaunchFrames) n.unit_frames = kMaxLaunchFrames;
     if (n.leaf_lanes > kWave) n.leaf_lanes = kWave;
     if (n.shade_lanes > kWave) n.shade_lanes = kWave;
+    n.no_cull = n.no_cull > 0 ? 1 : 0;
     s->tuning = n;
+    s->dev.cull_eps = n.no_cull ? __builtin_inff() : s->cull_eps;
+    return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
+    if (!s || !out) return set_error(RT_ERR_INVALID_ARG, "rt_scene_get_info: NULL argument");
+    out->n_triangles = s->nT, out->n_nodes = s->nN;
+    out->bvh_depth = s->max_stack - 1;
+    out->stack_spill = s->max_stack > kLdsDepth ? 1 : 0;
+    out->cull_enabled = (s->dev.cull_eps < __builtin_inff()) ? 1 : 0;
+    out->cull_eps = s->cull_eps;
+    out->device = s->device;
     return RT_OK;
 }
 
@@ -1434,7 +1509,7 @@ int rt_render(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_c
     return RT_OK;
 }
 
-int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out) {
+static int render_stats_impl(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out, int executed) {
     if (!out) return set_error(RT_ERR_INVALID_ARG, "rt_render_stats: out is NULL");
     const size_t bytes = (s && d && d->width > 0 && d->height > 0) ? (size_t)d->width * d->height * 3 * sizeof(float) : 0;
     float dummy = 0.0f;
@@ -1451,7 +1526,7 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     if (e == hipSuccess && frame_count > 0) {
         Workspace ws;
         rc = scene_workspace(s, d, frame_count, &ws);
-        if (rc == RT_OK) rc = launch_render<true>(s, d, frame_begin, frame_count, dev, st, nullptr, ws);
+        if (rc == RT_OK) rc = launch_render<true>(s, d, frame_begin, frame_count, dev, st, nullptr, ws, executed);
         if (rc == RT_OK) {
             e = hipDeviceSynchronize();
             if (e == hipSuccess) e = hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
@@ -1471,6 +1546,13 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
     out->paths = h[0], out->rays = h[1], out->internal_nodes = h[2], out->leaf_nodes = h[3];
     out->triangles_tested = h[4], out->hit_updates = h[5];
     return RT_OK;
+}
+
+int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out) {
+    return render_stats_impl(s, d, frame_begin, frame_count, out, 0);
+}
+int rt_render_stats_executed(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out) {
+    return render_stats_impl(s, d, frame_begin, frame_count, out, 1);
 }
 
 int rt_primary_hits_device(rt_scene* s, const rt_render_desc* d, int32_t* tri_dev, float* dist_dev, void* stream) {

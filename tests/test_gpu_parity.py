@@ -526,6 +526,9 @@ def test_synthetic_10m_window_bit_exact_with_stats(scene_synth10m, hdr_pair):
     st = sc.render_stats(d, 0, F)
     assert st == ost, (st, ost)
     assert ost["internal_nodes"] / ost["rays"] > 300
+    assert sc.info().cull_enabled == 1 and sc.info().stack_spill == 1
+    ex = sc.render_stats(d, 0, F, executed=True)  # the walk the timed kernel executes: culled, a subset of the reference's
+    assert ex["rays"] == ost["rays"] and ex["internal_nodes"] < 0.5 * ost["internal_nodes"]
     tri, dist = sc.primary_hits(rt.make_desc(W, H, eye=eye, camera_rotate=cam))
     otri, odist = O.primary_hits(tris, nodes, W, H, eye, cam)
     assert (tri >= 0).mean() > 0.5
@@ -561,3 +564,100 @@ def test_synthetic_10m_full_4k_properties(scene_synth10m, hdr_pair):
     A8, B8 = (x.reshape(45, 4, 80, 4, 3).mean((1, 3)) for x in (A, B))
     assert np.sqrt(np.mean((A8 - B8) ** 2)) <= 0.05
     assert abs(A.mean() - B.mean()) <= 0.03 * A.mean()
+
+
+# ---- closest-hit culling (hitAABB_cull): never changes a result --------------------------------------------------------
+
+def _sliver_soup(seed, scale=1.0, offset=0.0):
+    """A soup built to stress the culling margin: ordinary triangles plus needles (one tiny angle), slivers whose third vertex
+    is a few ulps off an edge, long thin axis-aligned strips lying in box faces, and exact duplicates (ties)."""
+    rng = np.random.RandomState(7000 + seed)
+    n = 600
+    c = rng.uniform(-1.5, 1.5, (n, 1, 3))
+    p = c + rng.normal(0, 0.2, (n, 3, 3))
+    k = n // 6
+    # needles: p3 almost on the segment p1 -> p2 extended
+    p[:k, 2] = p[:k, 0] + (p[:k, 1] - p[:k, 0]) * rng.uniform(0.2, 3.0, (k, 1)) + rng.normal(0, 1e-6, (k, 3))
+    # slivers: p3 = p2 + a few ulps
+    p[k:2 * k, 2] = p[k:2 * k, 1] * (1.0 + rng.choice([1, 2, 4, 64], (k, 1)) * 2.0 ** -23)
+    # axis-aligned strips 3.0 x 1e-3 in planes x = const (their boxes are flat)
+    x0 = rng.uniform(-1.5, 1.5, k)
+    y0 = rng.uniform(-1.5, 1.5, k)
+    p[2 * k:3 * k, 0] = np.stack([x0, y0, np.full(k, -1.5)], 1)
+    p[2 * k:3 * k, 1] = np.stack([x0, y0 + 1e-3, np.full(k, -1.5)], 1)
+    p[2 * k:3 * k, 2] = np.stack([x0, y0, np.full(k, 1.5)], 1)
+    p[3 * k:4 * k] = p[4 * k:5 * k]  # exact duplicates: ties between leaves
+    p = p * scale + offset
+    t = np.zeros((n, 36), np.float32)
+    t[:, 0:9] = p.reshape(n, 9)
+    nrm = rng.normal(0, 1, (n, 3, 3))
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    t[:, 9:18] = nrm.reshape(n, 9)
+    t[:, 18:21] = np.where(rng.rand(n, 1) < 0.05, rng.uniform(0, 4, (n, 3)), 0.0)
+    t[:, 21:24] = rng.rand(n, 3)
+    t[:, 24:34] = rng.rand(n, 10)
+    t[:, 34] = 1.0
+    mesh = rt.Mesh()
+    mesh.append(t)
+    nodes = mesh.buildBVHwithSAH(int(rng.choice([1, 2, 8]))) if seed % 2 == 0 else mesh.buildBVH(int(rng.choice([1, 4])))
+    return mesh.triangles(), nodes, rng
+
+
+@pytest.mark.parametrize("seed,scale,offset", [(0, 1.0, 0.0), (1, 1.0, 0.0), (2, 1e-3, 0.0), (3, 1.0, 900.0), (4, 250.0, 0.0), (5, 1.0, -37.5)])
+def test_culling_keeps_results_on_needles_slivers_and_flat_boxes(hdr_pair, seed, scale, offset):
+    """The product kernels skip subtrees whose inflated box starts beyond the closest hit (hitAABB_cull); the oracle, like the
+    reference, walks everything.  Needles, ulp-thin slivers, flat boxes, ties, tiny / huge / far-off-origin coordinates and
+    cameras inside, near and far: closest hits, images and the reference-walk statistics must not change, and the executed
+    walk must be a subset of the reference's."""
+    tris, nodes, rng = _sliver_soup(seed, scale, offset)
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    assert sc.info().cull_enabled == 1
+    ctr = np.array([offset] * 3, np.float32)
+    for r in (0.3 * scale, 2.5 * scale, 40.0 * scale):
+        eye, cam = rt.camera(float(rng.uniform(0, 360)), float(rng.uniform(-70, 70)), float(r))
+        eye = (eye + ctr).astype(np.float32)
+        W, H = 96, 64
+        tri, dist = sc.primary_hits(rt.make_desc(W, H, eye=eye, camera_rotate=cam))
+        otri, odist = O.primary_hits(tris, nodes, W, H, eye, cam)
+        assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist)), f"primary hits, r={r}"
+        d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+        img = sc.render(d, 1, 2)
+        ref, ost = O.render(tris, nodes, hdr, cache, W, H, 5, eye, cam, 1, 2)
+        _assert_images_equal(img, ref, f"sliver soup {seed}, r={r}")
+        assert sc.render_stats(d, 1, 2) == ost
+        ex = sc.render_stats(d, 1, 2, executed=True)
+        assert ex["rays"] == ost["rays"] and ex["paths"] == ost["paths"]
+        assert all(ex[k] <= ost[k] for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"))
+    # the same images with culling switched off through rt_tuning
+    sc.set_tuning(no_cull=1)
+    assert sc.info().cull_enabled == 0
+    _assert_images_equal(sc.render(d, 1, 2), ref, "no_cull")
+    assert sc.render_stats(d, 1, 2, executed=True)["internal_nodes"] >= ex["internal_nodes"]
+
+
+def test_culling_is_off_for_boxes_that_do_not_nest(scene_small, hdr_pair):
+    """A caller's BVH whose boxes do not contain their children (legal for the reference: it only ever tests boxes) cannot be
+    culled safely: the scene reports cull_enabled = 0 and still renders like the oracle on the same arrays."""
+    tris, nodes = scene_small
+    nodes = nodes.copy()
+    internal = [i for i in range(2, nodes.shape[0]) if nodes[i, 3] == 0]
+    i = internal[len(internal) // 2]
+    nodes[i, 6:9] += (nodes[i, 9:12] - nodes[i, 6:9]) * 0.25  # shrink an internal node's box: its children now stick out
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    assert sc.info().cull_enabled == 0
+    eye, cam = rt.camera(20.0, 15.0, 3.5)
+    d = rt.make_desc(80, 60, mode=5, eye=eye, camera_rotate=cam)
+    ref, ost = O.render(tris, nodes, hdr, cache, 80, 60, 5, eye, cam, 0, 3)
+    _assert_images_equal(sc.render(d, 0, 3), ref, "non-nested boxes")
+    assert sc.render_stats(d, 0, 3, executed=True)["internal_nodes"] <= ost["internal_nodes"]
+    tri, dist = sc.primary_hits(d)
+    otri, odist = O.primary_hits(tris, nodes, 80, 60, eye, cam)
+    assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
+
+
+def test_culling_is_on_for_the_bundled_scenes(scene_chap2, scene_chap4, scene_chap5):
+    for tris, nodes in (scene_chap2, scene_chap4, scene_chap5):
+        i = rt.Scene(tris, nodes).info()
+        assert i.cull_enabled == 1 and 0.0 < i.cull_eps < 1e-2
