@@ -223,6 +223,18 @@ int rt_render_stats_executed(rt_scene* s, const rt_render_desc* d, int frame_beg
  * reset != 0, measured with HIP events on the launch stream; *launches receives the count. */
 int rt_kernel_time_ms(float* avg_ms, int* launches, int reset);
 
+/* The same with the longest launch and the shader clock the path loop ran at: every wave of the path-loop kernel
+ * reports its lifetime in shader-clock ticks (s_memtime); the longest-lived wave spans its launch, so its lifetime /
+ * the longest launch's duration = the clock under this load (measured, not the 2.4 GHz of the data sheet).  Call after
+ * launches of ONE shape on `s` (the calling thread's timed launches since the last reset are assumed to be that
+ * scene's).  Synchronises the device. */
+typedef struct rt_kernel_timing_info {
+    float avg_ms, max_ms;
+    int32_t launches;
+    float shader_clock_mhz;
+} rt_kernel_timing_info;
+int rt_kernel_timing(rt_scene* s, rt_kernel_timing_info* out, int reset);
+
 #ifdef __cplusplus
 }
 #endif

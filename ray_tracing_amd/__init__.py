@@ -100,6 +100,11 @@ class SceneInfo(C.Structure):
                 ("cull_enabled", C.c_int32), ("cull_eps", C.c_float), ("device", C.c_int32)]
 
 
+class KernelTiming(C.Structure):
+    """rt_kernel_timing_info."""
+    _fields_ = [("avg_ms", C.c_float), ("max_ms", C.c_float), ("launches", C.c_int32), ("shader_clock_mhz", C.c_float)]
+
+
 class RtError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"[rt_status {code}] {msg}")
@@ -137,6 +142,7 @@ _lib.rt_primary_hits.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, 
 _lib.rt_primary_hits_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
 _lib.rt_render_stats_executed.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
+_lib.rt_kernel_timing.argtypes = [C.c_void_p, C.POINTER(KernelTiming), C.c_int]
 _lib.rt_kernel_time_ms.argtypes = [_f32p, C.POINTER(C.c_int), C.c_int]
 _lib.rt_hash_fnv1a64.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
 _lib.rt_hash_fnv1a64.restype = C.c_uint64
@@ -336,6 +342,12 @@ class Scene:
         for k, v in kw.items():
             setattr(t, k, int(v))
         _check(_lib.rt_scene_set_tuning(self._h, C.byref(t)))
+
+    def kernel_timing(self, reset: bool = True) -> KernelTiming:
+        """Average / longest path-loop launch (HIP events) and the shader clock it ran at, since the last reset."""
+        t = KernelTiming()
+        _check(_lib.rt_kernel_timing(self._h, C.byref(t), 1 if reset else 0))
+        return t
 
     def primary_hits(self, desc: RenderDesc):
         """Chapter-2 hitBVH (c2:490-513) for the un-jittered camera rays: (tri index int32, distance fp32)."""

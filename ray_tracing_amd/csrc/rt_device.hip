@@ -92,6 +92,7 @@ struct RenderParams {
     float* samples;        // radiance samples of this launch, [frame - frame_begin][pixel][3]
     const float2* sobol;   // this launch's sobolVec2(frame + 1, bounce) (f5:362-365, 883): [frame - frame_begin][bounce 0..3]
     unsigned* queue;       // work queues, one per XCD's band of tiles (64 B apart): the next unit (tile, frame group) of the band
+    unsigned long long* clk;  // [0]: longest wave lifetime in shader-clock ticks (s_memtime), max over launches since the last reset
     int unit_frames;       // frames per unit
     int* spill;            // global stack spill, [depth - kLdsDepth][thread]
     long long spill_stride;
@@ -398,6 +399,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     int* const stk_lds = &s_stack[lane];
     int* const stk_spill = SPILL ? (P.spill + ((long long)blockIdx.x * kWave + lane)) : nullptr;
     const long long stk_stride = P.spill_stride;
+    const long long wave_begin = clock64();  // s_memtime: shader-clock ticks
     Stats st = {0, 0, 0, 0, 0};
     unsigned long long paths = 0;
     unsigned dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // STATS builds: passes / active-lane sums per op
@@ -812,6 +814,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (lane == 0) dg[6]++, dg[7] += nD;
         }
     }
+    // the longest-lived wave spans the whole launch: its lifetime in ticks / the launch's duration = the shader clock
+    if (lane == 0) atomicMax(P.clk, (unsigned long long)(clock64() - wave_begin));
 #ifdef RT_OP_CYCLES
     if (lane == 0) {
         oc[3] = (unsigned long long)(clock64() - oc_begin);
@@ -1167,7 +1171,8 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     DeviceGuard guard(s->device);  // the caller's current device is restored on return
     if (!guard.ok) return fail(set_error(RT_ERR_HIP, "rt_scene_create: cannot make device %d current", s->device));
     HIPCHK_S(hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, s->device));
-    HIPCHK_S(hipMalloc((void**)&s->d_queue, 8 * 16 * sizeof(unsigned)));
+    HIPCHK_S(hipMalloc((void**)&s->d_queue, 8 * 16 * sizeof(unsigned) + 64));  // 8 queue counters + the wave-lifetime cell
+    HIPCHK_S(hipMemset(s->d_queue, 0, 8 * 16 * sizeof(unsigned) + 64));
     HIPCHK_S(hipMalloc((void**)&s->d_sobol, (size_t)kMaxLaunchFrames * 4 * sizeof(float2)));
     if (nT > 0) {
         HIPCHK_S(hipMalloc(&s->d_ttri, ttri.size() * 4));
@@ -1231,6 +1236,7 @@ static int check_desc(const rt_scene* s, const rt_render_desc* d, const char* wh
 // the scene (allocated / grown on demand); rt_render_device_noalloc carves it out of the static scratch array.
 struct Workspace {
     unsigned* queue = nullptr;     // 8 work-queue counters, 64 B apart
+    unsigned long long* clk = nullptr;  // longest wave lifetime (ticks)
     float2* sobol = nullptr;       // kMaxLaunchFrames x 4 Sobol pairs
     float* samples = nullptr;      // launch_frames x W x H x RGB
     int launch_frames = 0;         // frames per kernel launch that `samples` holds
@@ -1302,6 +1308,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
     P.accum = accum_dev;
     P.stats = stats_dev;
     P.queue = ws.queue;
+    P.clk = ws.clk;
     P.samples = ws.samples;
     P.sobol = ws.sobol;
     P.spill = ws.spill, P.spill_stride = ws.spill_stride;
@@ -1353,6 +1360,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
 // Workspace of the allocating entry points: buffers kept with the scene, grown when a call needs more.
 static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count, Workspace* ws) {
     ws->queue = s->d_queue;
+    ws->clk = (unsigned long long*)(s->d_queue + 8 * 16);  // behind the 8 queue counters; reset by rt_kernel_timing only
     ws->sobol = s->d_sobol;
     int rc = grow_scene_spill(s, (size_t)render_blocks(s) * kWave, &ws->spill, &ws->spill_stride);
     if (rc != RT_OK) return rc;
@@ -1380,6 +1388,7 @@ static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count
 // once per device, and is what kernels, memsets and copies receive.
 constexpr size_t kScratchBytes = (size_t)64 << 20;
 constexpr size_t kScratchQueueOff = 0;                                   // 8 counters, 64 B apart (512 B)
+constexpr size_t kScratchClkOff = 1024;                                  // longest wave lifetime (8 B)
 constexpr size_t kScratchSobolOff = 4096;                                // kMaxLaunchFrames x 4 x float2 = 32 KiB
 constexpr size_t kScratchBodyOff = 65536;                                // stack spill (deep trees), then the sample buffer
 static_assert(kScratchSobolOff + (size_t)kMaxLaunchFrames * 4 * sizeof(float2) <= kScratchBodyOff, "scratch header layout");
@@ -1464,6 +1473,7 @@ int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_beg
     if (rc != RT_OK) return rc;
     Workspace ws;
     ws.queue = (unsigned*)(base + kScratchQueueOff);
+    ws.clk = (unsigned long long*)(base + kScratchClkOff);
     ws.sobol = (float2*)(base + kScratchSobolOff);
     size_t off = kScratchBodyOff;
     const size_t threads = (size_t)render_blocks(s) * kWave;
@@ -1601,6 +1611,35 @@ int rt_primary_hits(rt_scene* s, const rt_render_desc* d, int32_t* tri_host, flo
     (void)hipFree(dt), (void)hipFree(dd);
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) return set_error(RT_ERR_HIP, "rt_primary_hits: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_kernel_timing(rt_scene* s, rt_kernel_timing_info* out, int reset) {
+    if (!s || !out) return set_error(RT_ERR_INVALID_ARG, "rt_kernel_timing: NULL argument");
+    GUARD_DEVICE(s);
+    double total = 0, mx = 0;
+    int n = 0;
+    for (auto& tl : g_launches) {
+        float ms = 0;
+        if (hipEventSynchronize(tl.b) == hipSuccess && hipEventElapsedTime(&ms, tl.a, tl.b) == hipSuccess) {
+            total += ms;
+            if (ms > mx) mx = ms;
+            ++n;
+        }
+    }
+    unsigned long long ticks = 0;
+    unsigned long long* cell = (unsigned long long*)(s->d_queue + 8 * 16);
+    HIPCHK(hipMemcpy(&ticks, cell, sizeof(ticks), hipMemcpyDeviceToHost));
+    out->avg_ms = n ? (float)(total / n) : 0.0f;
+    out->max_ms = (float)mx;
+    out->launches = n;
+    // the longest-lived wave of the longest launch spans that launch: ticks / duration = the shader clock it ran at
+    out->shader_clock_mhz = (mx > 0.0 && ticks) ? (float)((double)ticks / (mx * 1e3)) : 0.0f;
+    if (reset) {
+        HIPCHK(hipMemset(cell, 0, sizeof(ticks)));
+        for (auto& tl : g_launches) (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
+        g_launches.clear();
+    }
     return RT_OK;
 }
 

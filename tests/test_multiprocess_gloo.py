@@ -70,3 +70,26 @@ def test_spp_split_two_ranks_matches_single_process(tmp_path):
     # same samples, different fp32 summation order: equal to rounding, not to the bit
     assert np.allclose(got, ref_sum / n, rtol=1e-5, atol=1e-6)
     assert np.allclose(got, ref_mean, rtol=1e-4, atol=1e-5)      # and to the reference's running mean (f5:955)
+
+
+def test_bench_launches_its_own_ranks_and_verifies(tmp_path):
+    """`bench.py --gpus 2` without a torch.distributed environment starts its own 2 ranks (torch.distributed.run on 127.0.0.1),
+    partitions the frames, reduces once per step, forms the image on rank 0, checks it against a single-process render of the
+    same frames and prints ONE JSON line with n_gpus = 2 — here over gloo with the oracle as the stand-in renderer."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    env["OMP_NUM_THREADS"] = "2"
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, env.get("PYTHONPATH", "")])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "2",
+                        "--width", "40", "--height", "32", "--backend", "gloo", "--render-plugin", "rehearsal_plugin:make", "--verify"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size_seen"] == 2 and out["scaling"] == "weak"
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
+    assert out["verify"]["ok"] and out["verify"]["frames"] == 2 * 2 * 2

@@ -1,0 +1,35 @@
+"""Sweeps rt_tuning on config 5 (1080p, mode 5) and prints Mpaths/s per setting."""
+import itertools, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+import ray_tracing_amd as rt
+from ray_tracing_amd import scenes
+t, n = scenes.chap5_scene()
+hdr, cache = scenes.hdr_and_cache()
+sc = rt.Scene(t, n, hdr, cache, device=0)
+eye, cam = rt.camera(0.0, 20.0, 4.0)
+W, H = 1920, 1080
+d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+st = torch.cuda.current_stream().cuda_stream
+def run(spp, **kw):
+    sc.set_tuning()
+    sc.set_tuning(**kw)
+    sc.render_device(d, 0, spp, acc.data_ptr(), st); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(3):
+        sc.render_device(d, (i + 1) * spp, spp, acc.data_ptr(), st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print(f"{kw} spp {spp}: {W * H * spp / dt / 1e6:8.1f} Mpaths/s", flush=True)
+run(32)
+for sl in (32, 40, 56, 64):
+    run(32, shade_lanes=sl)
+for ll in (2, 4, 16, 32):
+    run(32, leaf_lanes=ll)
+for wb in (1000, 2000, 8000, 16000):
+    run(32, wait_budget=wb)
+for uf in (1, 4, 8):
+    run(32, unit_frames=uf)
+run(64, launch_frames=64)
+run(64, launch_frames=64, unit_frames=4)
