@@ -185,6 +185,10 @@ typedef struct rt_tuning {
     int32_t wait_budget;       /* lane-passes spent waiting that trigger the shade pass; default 4000 */
     int32_t no_cull;           /* > 0: walk every node whose box the ray hits, as the reference does (f5:295-307), instead
                                   of skipping subtrees that provably cannot hold a closer hit; default 0 (skip them) */
+    int32_t overlap_frames;    /* launches of fewer frames than this run their path-loop kernel on one of two internal
+                                  streams, so that consecutive launches (the reference's one frame per display(), c5:706-760)
+                                  overlap: the next one starts while the last paths of this one drain; the fold stays on the
+                                  caller's stream.  Default 8; 1 = never overlap; 1025 = always */
 } rt_tuning;
 int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out);
 int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t);
@@ -234,6 +238,32 @@ typedef struct rt_kernel_timing_info {
     float shader_clock_mhz;
 } rt_kernel_timing_info;
 int rt_kernel_timing(rt_scene* s, rt_kernel_timing_info* out, int reset);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Viewer semantics: the state and callbacks of the reference's interactive loop, without the window.
+ * lastFrame lives on the device (like the reference's texture); nothing is copied to the host until it is read.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct rt_viewer rt_viewer;
+/* main() state of c5:147-149, 705: rotatAngle = upAngle = 0, r = 4, frameCounter = 0, a black lastFrame. */
+int rt_viewer_create(rt_scene* scene, int width, int height, int mode, rt_viewer** out);
+void rt_viewer_destroy(rt_viewer* v);
+/* display(), c5:706-760, n_frames times: frames frameCounter .. frameCounter+n-1 into lastFrame, frameCounter += n.
+ * Asynchronous on hip_stream (consecutive one-frame calls overlap on the device, rt_tuning.overlap_frames). */
+int rt_viewer_display(rt_viewer* v, int n_frames, void* hip_stream);
+/* mouseDown / mouse / mouseWheel, c5:766-791: rotatAngle += 150*dx/512, upAngle += 150*dy/512 clamped to +-89,
+ * r -= 0.5*direction; every camera change sets frameCounter = 0, so the next frame replaces the picture (weight 1). */
+int rt_viewer_mouse_down(rt_viewer* v, double x, double y);
+int rt_viewer_mouse_drag(rt_viewer* v, double x, double y);
+int rt_viewer_mouse_wheel(rt_viewer* v, int direction);
+int rt_viewer_set_orbit(rt_viewer* v, float rotat_angle_deg, float up_angle_deg, float r); /* same, absolute */
+int rt_viewer_state(const rt_viewer* v, int* frame_counter, float* rotat_angle_deg, float* up_angle_deg, float* r);
+const float* rt_viewer_last_frame_device(const rt_viewer* v);      /* W*H*3 fp32, GL row order, device memory */
+int rt_viewer_read(rt_viewer* v, float* rgb_host, void* hip_stream); /* lastFrame -> host; synchronises hip_stream */
+int rt_viewer_save_png(rt_viewer* v, const char* path, void* hip_stream); /* pass3 tone-map + gamma, svpng */
+/* The sample loop of chapter 1 with its per-N-samples dump (path_tracing_1chap/path_tracing.cpp:407-483, 478-482):
+ * renders total_frames more frames and, whenever frameCounter reaches a multiple of dump_every (> 0), writes
+ * path_pattern (exactly one %d = the sample count, e.g. "test_path_tracing_spp%d.png").  dump_every = 0: no dumps. */
+int rt_viewer_render_progressive(rt_viewer* v, int total_frames, int dump_every, const char* path_pattern, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -91,7 +91,7 @@ class TraceStats(C.Structure):
 
 class Tuning(C.Structure):
     """rt_tuning: scheduling knobs of the path loop (they never change the image)."""
-    _fields_ = [(n, C.c_int32) for n in ("launch_frames", "unit_frames", "leaf_lanes", "shade_lanes", "wait_budget", "no_cull")]
+    _fields_ = [(n, C.c_int32) for n in ("launch_frames", "unit_frames", "leaf_lanes", "shade_lanes", "wait_budget", "no_cull", "overlap_frames")]
 
 
 class SceneInfo(C.Structure):
@@ -366,6 +366,70 @@ class Scene:
         fn = _lib.rt_render_stats_executed if executed else _lib.rt_render_stats
         _check(fn(self._h, C.byref(desc), frame_begin, frame_count, C.byref(st)))
         return st.as_dict()
+
+
+_lib.rt_viewer_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+_lib.rt_viewer_destroy.argtypes = [C.c_void_p]
+_lib.rt_viewer_destroy.restype = None
+_lib.rt_viewer_display.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+_lib.rt_viewer_mouse_down.argtypes = [C.c_void_p, C.c_double, C.c_double]
+_lib.rt_viewer_mouse_drag.argtypes = [C.c_void_p, C.c_double, C.c_double]
+_lib.rt_viewer_mouse_wheel.argtypes = [C.c_void_p, C.c_int]
+_lib.rt_viewer_set_orbit.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+_lib.rt_viewer_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), _f32p, _f32p, _f32p]
+_lib.rt_viewer_last_frame_device.argtypes = [C.c_void_p]
+_lib.rt_viewer_last_frame_device.restype = C.c_void_p
+_lib.rt_viewer_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.rt_viewer_save_png.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+_lib.rt_viewer_render_progressive.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
+
+
+class Viewer:
+    """The reference's interactive loop without the window (rt_viewer): display() / mouse() / mouseWheel() of
+    path_tracing_5chap.cpp:706-791 on a device-resident lastFrame."""
+
+    def __init__(self, scene: Scene, width: int = 512, height: int = 512, mode: int = RT_MODE_CHAP5):
+        self._scene = scene  # keep the scene alive
+        self.width, self.height = width, height
+        self._h = C.c_void_p()
+        _check(_lib.rt_viewer_create(scene._h, width, height, mode, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rt_viewer_destroy(self._h)
+            self._h = None
+
+    def display(self, n_frames: int = 1, stream: int = 0):
+        _check(_lib.rt_viewer_display(self._h, n_frames, C.c_void_p(stream)))
+
+    def mouseDown(self, x, y):
+        _check(_lib.rt_viewer_mouse_down(self._h, x, y))
+
+    def mouse(self, x, y):
+        _check(_lib.rt_viewer_mouse_drag(self._h, x, y))
+
+    def mouseWheel(self, direction: int):
+        _check(_lib.rt_viewer_mouse_wheel(self._h, direction))
+
+    def set_orbit(self, rotatAngle: float, upAngle: float, r: float):
+        _check(_lib.rt_viewer_set_orbit(self._h, rotatAngle, upAngle, r))
+
+    def state(self):
+        fc, ra, ua, r = C.c_int(), C.c_float(), C.c_float(), C.c_float()
+        _check(_lib.rt_viewer_state(self._h, C.byref(fc), C.byref(ra), C.byref(ua), C.byref(r)))
+        return {"frameCounter": fc.value, "rotatAngle": ra.value, "upAngle": ua.value, "r": r.value}
+
+    def read(self, stream: int = 0) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), np.float32)
+        _check(_lib.rt_viewer_read(self._h, out.ctypes.data, C.c_void_p(stream)))
+        return out
+
+    def save_png(self, path: str, stream: int = 0):
+        _check(_lib.rt_viewer_save_png(self._h, os.fsencode(path), C.c_void_p(stream)))
+
+    def render_progressive(self, total_frames: int, dump_every: int = 0, path_pattern: str | None = None, stream: int = 0):
+        _check(_lib.rt_viewer_render_progressive(self._h, total_frames, dump_every,
+                                                 os.fsencode(path_pattern) if path_pattern else None, C.c_void_p(stream)))
 
 
 def kernel_time_ms(reset: bool = True):

@@ -356,6 +356,7 @@ constexpr int kLaunchFrames = 32;  // frames per kernel launch (sample buffer = 
 constexpr int kUnitFrames = 2;     // frames per work unit (one 8x8 tile x this many frames = 128 samples)
 constexpr size_t kMaxSampleBytes = (size_t)4 << 30;
 constexpr int kMaxWidth = 65535, kMaxHeight = 32767;  // a pixel travels as (x | y << 16) in one int
+constexpr int kOverlapFrames = 8;  // launches of fewer frames overlap their neighbours (two workspace slots, internal streams)
 constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
 
 template <bool SPILL>
@@ -942,16 +943,28 @@ struct rt_scene {
     void* d_hdr = nullptr;
     void* d_cache = nullptr;
     void* d_cdir = nullptr;
-    int* d_spill = nullptr;
+    int* d_spill = nullptr;      // primary_kernel's global stack spill (deep trees)
     size_t spill_bytes = 0;
-    float* d_samples = nullptr;  // sample buffer of the path loop (one launch: W x H x frames x RGB)
-    size_t samples_bytes = 0;
-    float2* d_sobol = nullptr;   // Sobol pairs of the current launch's frames (kMaxLaunchFrames x 4)
-    unsigned* d_queue = nullptr; // work-queue counter of the path loop
+    // The path loop's workspace exists twice: consecutive launches alternate between the two slots, each with its own
+    // internal stream, so that launch k+1 starts while launch k drains its last paths and its samples are folded.
+    struct Slot {
+        int* d_spill = nullptr;      // global stack spill (deep trees)
+        size_t spill_bytes = 0;
+        float* d_samples = nullptr;  // sample buffer (one launch: W x H x frames x RGB)
+        size_t samples_bytes = 0;
+        float2* d_sobol = nullptr;   // Sobol pairs of the launch's frames (kMaxLaunchFrames x 4)
+        unsigned* d_queue = nullptr; // work-queue counters
+        hipStream_t stream = nullptr;        // the path-loop kernel of this slot runs here
+        hipEvent_t render_done = nullptr;    // recorded on `stream` after the path-loop kernel
+        hipEvent_t fold_done = nullptr;      // recorded on the caller's stream after the fold that read this slot's samples
+        bool fold_recorded = false;
+    } slot[2];
+    unsigned next_slot = 0;
+    unsigned long long* d_clk = nullptr;  // longest wave lifetime (ticks) since the last rt_kernel_timing reset
     float* d_frame = nullptr;    // rt_render: device copy of the caller's host accumulation buffer
     size_t frame_bytes = 0;
     int cu_count = 0;
-    rt_tuning tuning{kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0};
+    rt_tuning tuning{kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames};
     float cull_eps = 0.0f;       // scene part of the culling margin; +inf = the BVH / triangles do not allow culling
 };
 
@@ -978,9 +991,16 @@ int rt_init(int device) {
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     DeviceGuard guard(s->device);
+    (void)hipDeviceSynchronize();  // launches may still be in flight on the internal streams
     (void)hipFree(s->d_frame);
     (void)hipFree(s->d_ttri), (void)hipFree(s->d_dmat), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
-    (void)hipFree(s->d_cache), (void)hipFree(s->d_cdir), (void)hipFree(s->d_spill), (void)hipFree(s->d_samples), (void)hipFree(s->d_queue), (void)hipFree(s->d_sobol);
+    (void)hipFree(s->d_cache), (void)hipFree(s->d_cdir), (void)hipFree(s->d_spill), (void)hipFree(s->d_clk);
+    for (auto& sl : s->slot) {
+        (void)hipFree(sl.d_spill), (void)hipFree(sl.d_samples), (void)hipFree(sl.d_queue), (void)hipFree(sl.d_sobol);
+        if (sl.render_done) (void)hipEventDestroy(sl.render_done);
+        if (sl.fold_done) (void)hipEventDestroy(sl.fold_done);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    }
     delete s;
 }
 
@@ -1171,9 +1191,15 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     DeviceGuard guard(s->device);  // the caller's current device is restored on return
     if (!guard.ok) return fail(set_error(RT_ERR_HIP, "rt_scene_create: cannot make device %d current", s->device));
     HIPCHK_S(hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, s->device));
-    HIPCHK_S(hipMalloc((void**)&s->d_queue, 8 * 16 * sizeof(unsigned) + 64));  // 8 queue counters + the wave-lifetime cell
-    HIPCHK_S(hipMemset(s->d_queue, 0, 8 * 16 * sizeof(unsigned) + 64));
-    HIPCHK_S(hipMalloc((void**)&s->d_sobol, (size_t)kMaxLaunchFrames * 4 * sizeof(float2)));
+    HIPCHK_S(hipMalloc((void**)&s->d_clk, 64));
+    HIPCHK_S(hipMemset(s->d_clk, 0, 64));
+    for (auto& sl : s->slot) {
+        HIPCHK_S(hipMalloc((void**)&sl.d_queue, 8 * 16 * sizeof(unsigned)));
+        HIPCHK_S(hipMalloc((void**)&sl.d_sobol, (size_t)kMaxLaunchFrames * 4 * sizeof(float2)));
+        HIPCHK_S(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        HIPCHK_S(hipEventCreateWithFlags(&sl.render_done, hipEventDisableTiming));
+        HIPCHK_S(hipEventCreateWithFlags(&sl.fold_done, hipEventDisableTiming));
+    }
     if (nT > 0) {
         HIPCHK_S(hipMalloc(&s->d_ttri, ttri.size() * 4));
         HIPCHK_S(hipMemcpy(s->d_ttri, ttri.data(), ttri.size() * 4, hipMemcpyHostToDevice));
@@ -1233,14 +1259,21 @@ static int check_desc(const rt_scene* s, const rt_render_desc* d, const char* wh
 }
 
 // Device memory a launch needs beside the scene, the inputs and the outputs.  rt_render* takes it from buffers kept with
-// the scene (allocated / grown on demand); rt_render_device_noalloc carves it out of the static scratch array.
-struct Workspace {
+// the scene (allocated / grown on demand; two slots that consecutive launches alternate between, each with an internal
+// stream); rt_render_device_noalloc carves one slot out of the static scratch array and stays on the caller's stream.
+struct WorkSlot {
     unsigned* queue = nullptr;     // 8 work-queue counters, 64 B apart
-    unsigned long long* clk = nullptr;  // longest wave lifetime (ticks)
     float2* sobol = nullptr;       // kMaxLaunchFrames x 4 Sobol pairs
     float* samples = nullptr;      // launch_frames x W x H x RGB
-    int launch_frames = 0;         // frames per kernel launch that `samples` holds
     int* spill = nullptr;          // global part of the traversal stacks (deep trees only)
+    rt_scene::Slot* pipe = nullptr;  // non-NULL: run the path-loop kernel on pipe->stream, ordered by pipe's events
+};
+struct Workspace {
+    WorkSlot slot[2];
+    int n_slots = 1;
+    unsigned* next_slot = nullptr;  // which slot the next launch takes (kept with the scene)
+    unsigned long long* clk = nullptr;  // longest wave lifetime (ticks)
+    int launch_frames = 0;         // frames per kernel launch that `samples` holds
     long long spill_stride = 0;
     bool timed = false;            // bracket the path-loop kernel with HIP events (creates events: allocating callers only)
 };
@@ -1307,14 +1340,11 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
     P.max_bounce = d->max_bounce > 0 ? d->max_bounce : (d->mode == RT_MODE_CHAP5 ? 4 : 6);
     P.accum = accum_dev;
     P.stats = stats_dev;
-    P.queue = ws.queue;
     P.clk = ws.clk;
-    P.samples = ws.samples;
-    P.sobol = ws.sobol;
-    P.spill = ws.spill, P.spill_stride = ws.spill_stride;
+    P.spill_stride = ws.spill_stride;
     const int blocks = render_blocks(s);
     const int launch_frames = ws.launch_frames;
-    const bool spill = P.spill != nullptr;
+    const bool spill = ws.slot[0].spill != nullptr;
     const int n_tiles = ((d->width + 7) / 8) * ((d->height + 7) / 8);
     const int fold_blocks = (int)(((size_t)d->width * d->height + 255) / 256);
     for (int done = 0; done < frame_count; done += launch_frames) {
@@ -1322,22 +1352,29 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         P.frame_count = frame_count - done < launch_frames ? frame_count - done : launch_frames;
         const long long n_units = (long long)n_tiles * ((P.frame_count + P.unit_frames - 1) / P.unit_frames);
         const int grid = (int)(n_units < blocks ? n_units : blocks);  // persistent waves: at most what the device holds
-        HIPCHK(hipMemsetAsync(ws.queue, 0, 8 * 16 * sizeof(unsigned), stream));
+        // this launch's slot; with two slots the path-loop kernel runs on the slot's own stream: it needs nothing from the
+        // caller's stream (the scene is immutable, `accum` is only touched by the fold), so it may start while the previous
+        // launch — other slot — is still draining its last paths; the fold then waits for it on the caller's stream
+        const WorkSlot& w = ws.slot[ws.next_slot ? ((*ws.next_slot)++ % (unsigned)ws.n_slots) : 0];
+        P.queue = w.queue, P.samples = w.samples, P.sobol = w.sobol, P.spill = w.spill;
+        const hipStream_t rstream = w.pipe ? w.pipe->stream : stream;
+        if (w.pipe && w.pipe->fold_recorded) HIPCHK(hipStreamWaitEvent(rstream, w.pipe->fold_done, 0));  // its samples have been folded
+        HIPCHK(hipMemsetAsync(w.queue, 0, 8 * 16 * sizeof(unsigned), rstream));
         if (d->mode == RT_MODE_CHAP5)
-            hipLaunchKernelGGL(sobol_table_kernel, dim3((P.frame_count * 4 + 127) / 128), dim3(128), 0, stream, ws.sobol, P.frame_begin, P.frame_count);
+            hipLaunchKernelGGL(sobol_table_kernel, dim3((P.frame_count * 4 + 127) / 128), dim3(128), 0, rstream, w.sobol, P.frame_begin, P.frame_count);
         TimedLaunch tl{};
         const bool timed = ws.timed && !STATS;
         if (timed) {
             HIPCHK(hipEventCreate(&tl.a));
             HIPCHK(hipEventCreate(&tl.b));
-            HIPCHK(hipEventRecord(tl.a, stream));
+            HIPCHK(hipEventRecord(tl.a, rstream));
         }
 #define LAUNCH(MODE_)                                                                                 \
     do {                                                                                              \
         if (spill)                                                                                    \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, true>), dim3(grid), dim3(kWave), 0, stream, P);  \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, true>), dim3(grid), dim3(kWave), 0, rstream, P);  \
         else                                                                                          \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, false>), dim3(grid), dim3(kWave), 0, stream, P); \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, false>), dim3(grid), dim3(kWave), 0, rstream, P); \
     } while (0)
         if (d->mode == RT_MODE_CHAP5)
             LAUNCH(RT_MODE_CHAP5);
@@ -1348,35 +1385,71 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
 #undef LAUNCH
         HIPCHK(hipGetLastError());
         if (timed) {
-            HIPCHK(hipEventRecord(tl.b, stream));
+            HIPCHK(hipEventRecord(tl.b, rstream));
             remember_launch(tl);
+        }
+        if (w.pipe) {
+            HIPCHK(hipEventRecord(w.pipe->render_done, rstream));
+            HIPCHK(hipStreamWaitEvent(stream, w.pipe->render_done, 0));
         }
         hipLaunchKernelGGL(fold_kernel, dim3(fold_blocks), dim3(256), 0, stream, P);
         HIPCHK(hipGetLastError());
+        if (w.pipe) {
+            HIPCHK(hipEventRecord(w.pipe->fold_done, stream));
+            w.pipe->fold_recorded = true;
+        }
     }
     return RT_OK;
 }
 
-// Workspace of the allocating entry points: buffers kept with the scene, grown when a call needs more.
-static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count, Workspace* ws) {
-    ws->queue = s->d_queue;
-    ws->clk = (unsigned long long*)(s->d_queue + 8 * 16);  // behind the 8 queue counters; reset by rt_kernel_timing only
-    ws->sobol = s->d_sobol;
-    int rc = grow_scene_spill(s, (size_t)render_blocks(s) * kWave, &ws->spill, &ws->spill_stride);
-    if (rc != RT_OK) return rc;
+// Before a slot's buffer is freed or reused outside the pipeline: everything that touches it has finished.
+static void quiesce_slot(rt_scene::Slot& sl) {
+    if (!sl.fold_recorded) return;  // never used by an overlapped launch since the last time
+    (void)hipStreamSynchronize(sl.stream);
+    (void)hipEventSynchronize(sl.fold_done);
+    sl.fold_recorded = false;
+}
+
+// Workspace of the allocating entry points: buffers kept with the scene, grown when a call needs more.  `pipelined`:
+// both slots, path-loop kernels on the slots' streams; otherwise slot 0 alone on the caller's stream (statistics passes).
+static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count, Workspace* ws, bool pipelined) {
     // frames per kernel launch: bounded by the sample buffer (W x H x frames x RGB fp32)
     int launch_frames = s->tuning.launch_frames;
     if (launch_frames > frame_count) launch_frames = frame_count;
     const size_t per_frame = (size_t)d->width * d->height * 3 * sizeof(float);
     while (launch_frames > 1 && per_frame * launch_frames > kMaxSampleBytes) launch_frames >>= 1;
-    if (per_frame * launch_frames > s->samples_bytes) {
-        (void)hipFree(s->d_samples);
-        s->d_samples = nullptr, s->samples_bytes = 0;
-        if (hipMalloc((void**)&s->d_samples, per_frame * launch_frames) != hipSuccess)
-            return set_error(RT_ERR_OOM, "rt_render: cannot allocate the %zu-byte sample buffer", per_frame * launch_frames);
-        s->samples_bytes = per_frame * launch_frames;
+    const size_t threads = (size_t)render_blocks(s) * kWave;
+    const size_t spill = spill_bytes_needed(s, threads);
+    // short launches are dominated by ramp-up and drain (a launch ends with every wave finishing its last paths at falling
+    // lane utilisation): those overlap their neighbours.  Long launches stay on the caller's stream, one at a time, so that
+    // a kernel's duration means what it says (rt_kernel_time_ms, rocprofv3).
+    pipelined = pipelined && launch_frames < s->tuning.overlap_frames;
+    ws->n_slots = pipelined ? 2 : 1;
+    ws->next_slot = pipelined ? &s->next_slot : nullptr;
+    if (!pipelined) quiesce_slot(s->slot[0]);
+    for (int k = 0; k < ws->n_slots; ++k) {
+        rt_scene::Slot& sl = s->slot[k];
+        if (per_frame * launch_frames > sl.samples_bytes) {
+            quiesce_slot(sl);
+            (void)hipFree(sl.d_samples);
+            sl.d_samples = nullptr, sl.samples_bytes = 0;
+            if (hipMalloc((void**)&sl.d_samples, per_frame * launch_frames) != hipSuccess)
+                return set_error(RT_ERR_OOM, "rt_render: cannot allocate the %zu-byte sample buffer", per_frame * launch_frames);
+            sl.samples_bytes = per_frame * launch_frames;
+        }
+        if (spill > sl.spill_bytes) {
+            quiesce_slot(sl);
+            (void)hipFree(sl.d_spill);
+            sl.d_spill = nullptr, sl.spill_bytes = 0;
+            HIPCHK(hipMalloc((void**)&sl.d_spill, spill));
+            sl.spill_bytes = spill;
+        }
+        ws->slot[k].queue = sl.d_queue, ws->slot[k].sobol = sl.d_sobol, ws->slot[k].samples = sl.d_samples;
+        ws->slot[k].spill = spill ? sl.d_spill : nullptr;
+        ws->slot[k].pipe = pipelined ? &sl : nullptr;
     }
-    ws->samples = s->d_samples;
+    ws->clk = s->d_clk;
+    ws->spill_stride = spill ? (long long)threads : 0;
     ws->launch_frames = launch_frames;
     ws->timed = true;
     return RT_OK;
@@ -1424,7 +1497,7 @@ int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out) {
 
 int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     if (!s) return set_error(RT_ERR_INVALID_ARG, "rt_scene_set_tuning: NULL scene");
-    const rt_tuning def = {kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0};
+    const rt_tuning def = {kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames};
     rt_tuning n = t ? *t : def;
     if (n.launch_frames <= 0) n.launch_frames = def.launch_frames;
     if (n.unit_frames <= 0) n.unit_frames = def.unit_frames;
@@ -1436,6 +1509,7 @@ int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     if (n.leaf_lanes > kWave) n.leaf_lanes = kWave;
     if (n.shade_lanes > kWave) n.shade_lanes = kWave;
     n.no_cull = n.no_cull > 0 ? 1 : 0;
+    if (n.overlap_frames <= 0) n.overlap_frames = def.overlap_frames;
     s->tuning = n;
     s->dev.cull_eps = n.no_cull ? __builtin_inff() : s->cull_eps;
     return RT_OK;
@@ -1458,7 +1532,7 @@ int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int 
     if (frame_count == 0) return RT_OK;
     GUARD_DEVICE(s);
     Workspace ws;
-    rc = scene_workspace(s, d, frame_count, &ws);
+    rc = scene_workspace(s, d, frame_count, &ws, true);
     if (rc != RT_OK) return rc;
     return launch_render<false>(s, d, frame_begin, frame_count, accum_dev, nullptr, (hipStream_t)stream, ws);
 }
@@ -1471,10 +1545,10 @@ int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_beg
     unsigned char* base = nullptr;
     rc = scratch_address(s->device, &base);  // looked up at rt_init / rt_scene_create; here only if neither ran on this device
     if (rc != RT_OK) return rc;
-    Workspace ws;
-    ws.queue = (unsigned*)(base + kScratchQueueOff);
+    Workspace ws;  // one slot, everything on the caller's stream
+    ws.slot[0].queue = (unsigned*)(base + kScratchQueueOff);
     ws.clk = (unsigned long long*)(base + kScratchClkOff);
-    ws.sobol = (float2*)(base + kScratchSobolOff);
+    ws.slot[0].sobol = (float2*)(base + kScratchSobolOff);
     size_t off = kScratchBodyOff;
     const size_t threads = (size_t)render_blocks(s) * kWave;
     const size_t spill = spill_bytes_needed(s, threads);
@@ -1482,7 +1556,7 @@ int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_beg
         return set_error(RT_ERR_INVALID_ARG, "rt_render_device_noalloc: a BVH of depth %d needs %zu bytes of stack spill; the static scratch holds %zu",
                          s->max_stack - 1, spill, kScratchBytes - off);
     if (spill) {
-        ws.spill = (int*)(base + off), ws.spill_stride = (long long)threads;
+        ws.slot[0].spill = (int*)(base + off), ws.spill_stride = (long long)threads;
         off += (spill + 255) & ~(size_t)255;
     }
     const size_t per_frame = (size_t)d->width * d->height * 3 * sizeof(float);
@@ -1493,7 +1567,7 @@ int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_beg
     size_t lf = room / per_frame;
     if (lf > (size_t)s->tuning.launch_frames) lf = (size_t)s->tuning.launch_frames;
     if (lf > (size_t)frame_count) lf = (size_t)frame_count;
-    ws.samples = (float*)(base + off);
+    ws.slot[0].samples = (float*)(base + off);
     ws.launch_frames = (int)lf;
     ws.timed = false;  // hipEventCreate allocates
     return launch_render<false>(s, d, frame_begin, frame_count, accum_dev, nullptr, (hipStream_t)stream, ws);
@@ -1535,7 +1609,7 @@ static int render_stats_impl(rt_scene* s, const rt_render_desc* d, int frame_beg
     unsigned long long h[26] = {0};
     if (e == hipSuccess && frame_count > 0) {
         Workspace ws;
-        rc = scene_workspace(s, d, frame_count, &ws);
+        rc = scene_workspace(s, d, frame_count, &ws, false);
         if (rc == RT_OK) rc = launch_render<true>(s, d, frame_begin, frame_count, dev, st, nullptr, ws, executed);
         if (rc == RT_OK) {
             e = hipDeviceSynchronize();
@@ -1628,7 +1702,7 @@ int rt_kernel_timing(rt_scene* s, rt_kernel_timing_info* out, int reset) {
         }
     }
     unsigned long long ticks = 0;
-    unsigned long long* cell = (unsigned long long*)(s->d_queue + 8 * 16);
+    unsigned long long* cell = s->d_clk;
     HIPCHK(hipMemcpy(&ticks, cell, sizeof(ticks), hipMemcpyDeviceToHost));
     out->avg_ms = n ? (float)(total / n) : 0.0f;
     out->max_ms = (float)mx;

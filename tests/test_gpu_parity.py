@@ -661,3 +661,81 @@ def test_culling_is_on_for_the_bundled_scenes(scene_chap2, scene_chap4, scene_ch
     for tris, nodes in (scene_chap2, scene_chap4, scene_chap5):
         i = rt.Scene(tris, nodes).info()
         assert i.cull_enabled == 1 and 0.0 < i.cull_eps < 1e-2
+
+
+# ---- viewer semantics in the C ABI ----------------------------------------------------------------------------
+
+def test_viewer_display_mouse_and_wheel_follow_the_reference_loop(scene_small, hdr_pair, tmp_path):
+    """rt_viewer = display() / mouse() / mouseWheel() of path_tracing_5chap.cpp:706-791 on a device-resident lastFrame: one frame
+    per display() call (overlapped on the device) equals the oracle's running mean; a camera change resets frameCounter, so the
+    next frame replaces the picture; the per-N-samples dump of chapter 1 (path_tracing.cpp:478-482) writes the tone-mapped PNGs."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    W, H = 72, 56
+    v = rt.Viewer(sc, W, H, rt.RT_MODE_CHAP5)
+    assert v.state() == {"frameCounter": 0, "rotatAngle": 0.0, "upAngle": 0.0, "r": 4.0}  # c5:147-149, 705
+    v.mouseDown(100, 100)
+    v.mouse(150, 140)  # rotatAngle += 150*50/512, upAngle += 150*40/512 (c5:770-771)
+    st = v.state()
+    assert st["frameCounter"] == 0
+    assert np.float32(st["rotatAngle"]) == np.float32(150 * 50 / 512) and np.float32(st["upAngle"]) == np.float32(150 * 40 / 512)
+    for _ in range(7):
+        v.display()  # seven display() calls, one frame each
+    assert v.state()["frameCounter"] == 7
+    eye, cam = rt.camera(st["rotatAngle"], st["upAngle"], 4.0)
+    ref, _ = O.render(tris, nodes, hdr, cache, W, H, 5, eye, cam, 0, 7)
+    _assert_images_equal(v.read(), ref, "7 x display()")
+    v.mouseWheel(1)  # r -= 0.5, frameCounter = 0 (c5:788-789): the old picture is replaced, not blended
+    assert v.state()["r"] == 3.5 and v.state()["frameCounter"] == 0
+    v.display(3)
+    eye2, cam2 = rt.camera(st["rotatAngle"], st["upAngle"], 3.5)
+    ref2, _ = O.render(tris, nodes, hdr, cache, W, H, 5, eye2, cam2, 0, 3)
+    _assert_images_equal(v.read(), ref2, "after mouseWheel")
+    v.mouse(150, 10000)  # upAngle is clamped to 89 (c5:772)
+    assert v.state()["upAngle"] == 89.0
+    # progressive dumps every 2 samples, chapter-1 style file names
+    v.set_orbit(20.0, 15.0, 3.5)
+    v.render_progressive(5, 2, str(tmp_path / "test_path_tracing_spp%d.png"))
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["test_path_tracing_spp2.png", "test_path_tracing_spp4.png"]
+    eye3, cam3 = rt.camera(20.0, 15.0, 3.5)
+    ref4, _ = O.render(tris, nodes, hdr, cache, W, H, 5, eye3, cam3, 0, 4)
+    want = tmp_path / "want.png"
+    rt.write_png(str(want), O.tonemap_rgb8(ref4))
+    assert (tmp_path / "test_path_tracing_spp4.png").read_bytes() == want.read_bytes()
+    ref5, _ = O.render(tris, nodes, hdr, cache, W, H, 5, eye3, cam3, 0, 5)
+    _assert_images_equal(v.read(), ref5, "after the progressive loop")
+    with pytest.raises(rt.RtError):
+        v.render_progressive(2, 1, str(tmp_path / "no_conversion.png"))
+    with pytest.raises(rt.RtError):
+        v.render_progressive(2, 1, str(tmp_path / "%s.png"))
+
+
+def test_one_frame_calls_overlap_and_stay_bit_exact(scene_chap5, hdr_pair):
+    """The reference's calling pattern — one frame per call — runs its path-loop kernels on two alternating internal streams
+    (rt_tuning.overlap_frames) while the folds stay in order on the caller's stream: 40 one-frame calls at 1080p equal one
+    40-frame call and the same calls with overlap switched off, to the bit."""
+    import torch
+    tris, nodes = scene_chap5
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache, device=0)
+    eye, cam = rt.camera(0.0, 20.0, 4.0)
+    W, H, F = 1920, 1080, 40
+    d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+    st = torch.cuda.current_stream().cuda_stream
+    bufs = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0") for _ in range(3)]
+    for f in range(F):
+        sc.render_device(d, f, 1, bufs[0].data_ptr(), st)       # overlapped one-frame calls
+    sc.render_device(d, 0, F, bufs[1].data_ptr(), st)           # one call (two launches of <= 32 frames)
+    sc.set_tuning(overlap_frames=1)                             # never overlap
+    for f in range(F):
+        sc.render_device(d, f, 1, bufs[2].data_ptr(), st)
+    torch.cuda.synchronize()
+    a, b, c = (x.cpu().numpy() for x in bufs)
+    _assert_images_equal(a, b, "40 overlapped one-frame calls vs one call")
+    _assert_images_equal(c, b, "40 serial one-frame calls vs one call")
+    sc.set_tuning(overlap_frames=1025, launch_frames=3)         # always overlap, many short launches inside one call
+    bufs[0].zero_()
+    sc.render_device(d, 0, F, bufs[0].data_ptr(), st)
+    torch.cuda.synchronize()
+    _assert_images_equal(bufs[0].cpu().numpy(), b, "one call cut into 14 overlapped launches")
