@@ -33,7 +33,7 @@ cd "$root"
 if [ -z "$quick" ]; then
 timeout -k 10 600 python3 -u tools/baselines.py > "$out/baselines.log" 2>&1 || { tail "$out/baselines.log"; exit 1; }
 # the synthetic ~10 M-triangle workload at 4K (BASELINE configs[4]); the scene build is cached under /tmp for the passes
-SYN="--scene synthetic --width 3840 --height 2160 --spp 4 --no-cpu-baseline"
+SYN="--scene synthetic --width 3840 --height 2160 --spp 8 --no-cpu-baseline"
 timeout -k 10 600 python3 "$B" $SYN --steps 4 --warmup 1 > "$out/syn_bench.json.log" 2> "$out/syn_bench.err" || { tail "$out/syn_bench.err"; exit 1; }
 cd /tmp
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d "$out/syn_stats" -o r -- python3 "$B" $SYN --steps 4 --warmup 1 > "$out/syn_bench_under_rocprof.log" 2>&1 || exit 1
@@ -42,5 +42,11 @@ pmc syn_pmc_fetch FETCH_SIZE TCC_HIT_sum -- $SYN --steps 1 --warmup 1 --no-stats
 pmc syn_pmc_write WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -- $SYN --steps 1 --warmup 1 --no-stats
 cd "$root"
 fi
-tail -1 "$out/bench.json.log" | cut -c1-400
-find "$out" -name "*.db" | head -20
+# summarise on the box and drop the rocprofv3 databases (gpurun copies back at most 64 MiB)
+mkdir -p "$out/summary"
+cp profiles/hbm_traffic.json "$out/summary/hbm_traffic.json" 2>/dev/null
+python3 tools/summarize_profiles.py "$out" "$out/summary/$tag" > "$out/summary/summarize.log" 2>&1 || { tail "$out/summary/summarize.log"; exit 1; }
+find "$out" -name "*.db" -delete
+find "$out" -type d -empty -delete
+tail -1 "$out/bench.json.log" | cut -c1-300
+du -sh "$out"
