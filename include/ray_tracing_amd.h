@@ -131,6 +131,14 @@ int rt_init(int device);
 typedef struct rt_scene rt_scene;
 int rt_scene_create(const float* tris, int n_triangles, const float* nodes, int n_nodes, const float* hdr_map,
                     const float* hdr_cache, int hdr_width, int hdr_height, rt_scene** out);
+/* The same with options (NULL = defaults).  No counterpart in the reference. */
+typedef struct rt_scene_options {
+    int32_t entry_bvh;         /* 0: build the device-private entry BVH (rt_tuning.no_entry_bvh) where the caller's BVH is expensive
+                                  to walk (cost_reference_tree > 32, >= 1024 triangles, at least twice as cheap); 1: always build
+                                  it (if the BVH allows culling at all); -1: never */
+} rt_scene_options;
+int rt_scene_create_ex(const float* tris, int n_triangles, const float* nodes, int n_nodes, const float* hdr_map,
+                       const float* hdr_cache, int hdr_width, int hdr_height, const rt_scene_options* options, rt_scene** out);
 void rt_scene_destroy(rt_scene* s);
 
 enum { RT_MODE_CHAP3 = 3, RT_MODE_CHAP4 = 4, RT_MODE_CHAP5 = 5 }; /* which fshader.fsh main() to run */
@@ -189,6 +197,11 @@ typedef struct rt_tuning {
                                   streams, so that consecutive launches (the reference's one frame per display(), c5:706-760)
                                   overlap: the next one starts while the last paths of this one drain; the fold stays on the
                                   caller's stream.  Default 8; 1 = never overlap; 1025 = always */
+    int32_t no_entry_bvh;      /* > 0: never walk the entry BVH.  Where the caller's BVH is expensive to walk (the reference's
+                                  INF = 114514 median splits, c5:500-502, on large scenes: cost_reference_tree > 32) rt_scene_create
+                                  builds a private binned-SAH tree over the same triangles; a ray walks it first, with a
+                                  conservative box test, to get a distance bound or to prove it hits nothing, and the caller's
+                                  BVH — which alone decides the result — only inside that bound.  Same images, fewer nodes. */
 } rt_tuning;
 int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out);
 int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t);
@@ -204,6 +217,9 @@ typedef struct rt_scene_info {
     float cull_eps;            /* scene part of a ray's culling margin: 2^-13 * scene extent (each box adds the shape
                                   term of the worst triangle below it: 2^-14 * longest edge / sin(min angle / 2)) */
     int32_t device;
+    int32_t entry_bvh;         /* 1: the path loop walks a device-private binned-SAH tree first (see rt_tuning.no_entry_bvh) */
+    float cost_reference_tree; /* expected internal nodes a random line through the root box visits: the caller's BVH ... */
+    float cost_entry_bvh;      /* ... and the entry BVH (0 when none was built) */
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
 

@@ -91,13 +91,14 @@ class TraceStats(C.Structure):
 
 class Tuning(C.Structure):
     """rt_tuning: scheduling knobs of the path loop (they never change the image)."""
-    _fields_ = [(n, C.c_int32) for n in ("launch_frames", "unit_frames", "leaf_lanes", "shade_lanes", "wait_budget", "no_cull", "overlap_frames")]
+    _fields_ = [(n, C.c_int32) for n in ("launch_frames", "unit_frames", "leaf_lanes", "shade_lanes", "wait_budget", "no_cull", "overlap_frames", "no_entry_bvh")]
 
 
 class SceneInfo(C.Structure):
     """rt_scene_info."""
     _fields_ = [("n_triangles", C.c_int32), ("n_nodes", C.c_int32), ("bvh_depth", C.c_int32), ("stack_spill", C.c_int32),
-                ("cull_enabled", C.c_int32), ("cull_eps", C.c_float), ("device", C.c_int32)]
+                ("cull_enabled", C.c_int32), ("cull_eps", C.c_float), ("device", C.c_int32), ("entry_bvh", C.c_int32),
+                ("cost_reference_tree", C.c_float), ("cost_entry_bvh", C.c_float)]
 
 
 class KernelTiming(C.Structure):
@@ -130,6 +131,8 @@ _lib.rt_free.argtypes = [C.c_void_p]
 _lib.rt_free.restype = None
 _lib.rt_scene_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.POINTER(C.c_void_p)]
+_lib.rt_scene_create_ex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_void_p, C.POINTER(C.c_void_p)]
 _lib.rt_scene_destroy.argtypes = [C.c_void_p]
 _lib.rt_scene_destroy.restype = None
 _lib.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p]
@@ -279,7 +282,7 @@ class Scene:
     """Device-resident scene: what c5:881-909 uploads (triangles TBO, nodes TBO, hdrMap, hdrCache)."""
 
     def __init__(self, triangles: np.ndarray, nodes: np.ndarray, hdr: np.ndarray | None = None,
-                 hdr_cache: np.ndarray | None = None, device: int | None = None):
+                 hdr_cache: np.ndarray | None = None, device: int | None = None, entry_bvh: int = 0):
         if device is not None:
             _check(_lib.rt_init(device))
         tris = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 36)
@@ -296,9 +299,10 @@ class Scene:
                 assert hdr_cache.shape == hdr.shape
                 cp = hdr_cache.ctypes.data
         self._h = C.c_void_p()
-        _check(_lib.rt_scene_create(tris.ctypes.data if tris.size else None, tris.shape[0],
-                                    nd.ctypes.data if nd.size else None, nd.shape[0], hp, cp, hw, hh,
-                                    C.byref(self._h)))
+        opt = (C.c_int32 * 1)(entry_bvh)  # rt_scene_options
+        _check(_lib.rt_scene_create_ex(tris.ctypes.data if tris.size else None, tris.shape[0],
+                                       nd.ctypes.data if nd.size else None, nd.shape[0], hp, cp, hw, hh,
+                                       C.cast(opt, C.c_void_p), C.byref(self._h)))
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:  # (_lib is None while the interpreter shuts down)

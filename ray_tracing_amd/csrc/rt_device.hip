@@ -73,6 +73,13 @@ struct DevScene {
     int has_root;
     float cull_eps;       // scene part of a ray's culling margin (see hitAABB_cull); +inf = this scene is never culled
     float cull_geo_max;   // largest finite per-box margin of the node records
+    const float4* nodes2; // entry BVH: node records (same layout as `nodes`) ...
+    const float4* ttri2;  // ... and its triangles (same layout as `ttri`), in its own leaf order
+    const int* map2;      // entry-BVH triangle -> index in the caller's order
+    const int* leafx;     // per triangle (caller's order): where its leaf's box lives = (record << 1 | side)
+    const int* parentx;   // per record of `nodes`: where that node's own box lives = (parent record << 1 | side); -1 = root
+    int root_entry2;
+    int has_entry;        // walk the entry BVH first (phase 0), then check its answer against the reference tree (phase 1)
 };
 
 // packed stack entry: >= 0 internal record index; < 0 leaf: bit31 | (n-1) << 24 | first triangle index
@@ -344,7 +351,7 @@ __device__ __forceinline__ void flush_stats(const RenderParams& P, const Stats& 
 // running while lanes accumulate at the expensive shade pass, so each shade pass is executed by many lanes, whatever
 // frame, bounce or ray kind each lane is in.  Per lane the sequence of nodes, leaves, triangles, arithmetic and RNG
 // calls is exactly the reference's.
-enum LaneOp { OP_INT = 0, OP_LEAF = 1, OP_H = 2, OP_DONE = 3 };
+enum LaneOp { OP_INT = 0, OP_LEAF = 1, OP_H = 2, OP_DONE = 3, OP_END = 4 /* transient: the walk of the current phase just ended */ };
 enum RayKind { K_PRIMARY = 0, K_SHADOW = 1, K_BOUNCE = 2, K_NONE = 3 };
 
 constexpr int kWaitBudget = 4000;  // lane-passes; of the order of (VALU cost of a shade pass) / (one lane's share of a traversal pass)
@@ -384,13 +391,14 @@ __device__ __forceinline__ int wave_inclusive_sum(int x) {
     return x;
 }
 
-template <int MODE, bool STATS, bool SPILL>
+template <int MODE, bool STATS, bool SPILL, bool ENTRY>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU))) render_kernel(const RenderParams P) {
     __shared__ int s_stack[kLdsDepth * kWave];        // per-lane traversal stacks, [depth][lane]
     __shared__ float4 s_ray[2 * kWave];                // per-lane ray in flight: (S.xyz, d.x) (d.yz, -, -)
     __shared__ int s_item[kWave];                      // cooperative leaf pass: item -> (triangle << 6 | owner lane)
     __shared__ unsigned long long s_key[kWave];        // per owner: min over its items of (t bits << 32 | triangle)
     __shared__ float s_t[kWave];                       // STATS builds: per item hit distance (INF = miss)
+    __shared__ int s_tie[ENTRY ? kWave : 1];           // entry-BVH walks: per owner, two of its items share the smallest t
     const DevScene& sc = P.sc;
     const int lane = threadIdx.x;
     const int tilesx = (P.width + 7) >> 3, n_tiles = tilesx * ((P.height + 7) >> 3);
@@ -419,6 +427,20 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     // statistics builds walk exactly the reference's nodes (algorithmic counts) unless asked for the executed walk
     const bool CULL = !STATS || P.stats_executed != 0;
     float ceps = __builtin_inff();  // culling margin of the ray in flight (hitAABB_cull); +inf = never cull
+    // Which tree the ray in flight is walking (ENTRY instantiations; otherwise always 2).
+    //   0: the entry BVH — a device-private binned-SAH tree over the same triangles, walked with the conservative box test
+    //      (hitAABB_cull's inflated box: it never rejects a box that holds a triangle hitTriangle would accept), so it sees
+    //      every acceptable triangle: no hit there = no hit for the reference, and its closest hit W at t_W is the closest
+    //      acceptable hit overall;
+    //   1: check W against the reference tree: the reference finds W iff every box from W's leaf up to (not including) the
+    //      root passes the reference's own test for this ray (f5:282-307) — one box per internal-node pass, bottom-up.  All
+    //      pass and W is the only triangle at t_W => W at t_W is the reference's answer (its candidates are a subset of the
+    //      acceptable triangles and W is the minimum of the superset);
+    //   2: the reference's own walk (no entry BVH; rays that must not be culled; a failed check; a tie at t_W, where the
+    //      reference's visit order decides; env-visibility rays whose first hit failed the check).
+    // Phases 1 / 2 alone decide results; the entry BVH only decides how much of the reference tree has to be walked.
+    int phase = 2;
+    bool tie = false;               // phase 0: another triangle has exactly the closest distance
     int cur = 0, sp = 0, best_tri = -1, ti = 0;        // ti: next triangle of the leaf in `cur`
     float best = INF_;
     float leaf_best = INF_;         // STATS only
@@ -662,12 +684,15 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (STATS) { const int c_ = __popcll(__ballot(emit)); if (lane == 0) sg[6] += c_; }
             if (emit) {
                 if (STATS) st.rays++;
-                best = INF_, best_tri = -1, sp = 0, cur = sc.root_entry;
+                best = INF_, best_tri = -1, sp = 0;
                 invdir = v3(1.0f) / d;
                 slow = !(finite3(invdir) && finite3(S));
                 ceps = CULL ? cull_margin(sc.cull_eps, sc.cull_geo_max, S, invdir, slow) : __builtin_inff();
+                phase = (ENTRY && ceps < __builtin_inff()) ? 0 : 2;
+                tie = false;
+                cur = (ENTRY && phase == 0) ? sc.root_entry2 : sc.root_entry;
                 s_ray[2 * lane] = make_float4(S.x, S.y, S.z, d.x);  // for the cooperative leaf pass
-                s_ray[2 * lane + 1] = make_float4(d.y, d.z, 0.0f, 0.0f);
+                s_ray[2 * lane + 1] = make_float4(d.y, d.z, __int_as_float(phase), 0.0f);
                 if (!sc.has_root) {
                     op = OP_H;
                 } else if (cur >= 0) {
@@ -681,24 +706,50 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             // ---- one internal node (f5:282-307) ------------------------------------------------------------------
             if (op == OP_INT) {
                 if (STATS) st.internal++;
-                const float4 q0 = sc.nodes[cur * 4 + 0], q1 = sc.nodes[cur * 4 + 1], q2 = sc.nodes[cur * 4 + 2];
-                const float4 q3 = sc.nodes[cur * 4 + 3];  // the two child entries, the two children's culling margins
+                const float4* nb = (ENTRY && phase == 0) ? sc.nodes2 : sc.nodes;
+                const int rec = (ENTRY && phase == 1) ? (cur >> 1) : cur;  // phase 1: cur = (record << 1 | side) of the box to check
+                const float4 q0 = nb[rec * 4 + 0], q1 = nb[rec * 4 + 1], q2 = nb[rec * 4 + 2];
+                const float4 q3 = nb[rec * 4 + 3];  // the two child entries, the two children's culling margins
                 const vec3 lAA = v3(q0.x, q0.y, q0.z), lBB = v3(q0.w, q1.x, q1.y);
                 const vec3 rAA = v3(q1.z, q1.w, q2.x), rBB = v3(q2.y, q2.z, q2.w);
                 // a child whose inflated box starts beyond the closest hit so far cannot change the result: skip it
                 // (ceps = +inf for rays that must not be culled: then c1 = c2 = -inf)
-                float c1, c2;
-                float d1 = hitAABB_cull(S, invdir, lAA, lBB, ceps, q3.z, &c1);
-                float d2 = hitAABB_cull(S, invdir, rAA, rBB, ceps, q3.w, &c2);
-                if (c1 > best) d1 = -1.0f;
-                if (c2 > best) d2 = -1.0f;
+                float c1, c2, e1, e2;
+                float d1 = hitAABB_cull(S, invdir, lAA, lBB, ceps, q3.z, &c1, ENTRY ? &e1 : nullptr);
+                float d2 = hitAABB_cull(S, invdir, rAA, rBB, ceps, q3.w, &c2, ENTRY ? &e2 : nullptr);
+                bool verified = false, refuted = false;
+                if (ENTRY && phase == 1) {
+                    // the reference's own test of one box on the way up from W's leaf (never culled: ceps is finite here, so
+                    // no operand is NaN and d1 / d2 are the ternary form's values)
+                    const float dv = (cur & 1) ? d2 : d1;
+                    if (dv > 0.0f) {
+                        const int up = sc.parentx[rec];
+                        if (up < 0) verified = true; else cur = up;
+                    } else {
+                        refuted = true;
+                    }
+                    d1 = d2 = -1.0f;
+                } else if (ENTRY && phase == 0) {  // entry BVH: the conservative test alone (hitAABB_entry), near child first by entry distance
+                    d1 = (c1 <= e1 && e1 >= 0.0f && c1 <= best) ? __builtin_fmaxf(c1, 1e-30f) : -1.0f;
+                    d2 = (c2 <= e2 && e2 >= 0.0f && c2 <= best) ? __builtin_fmaxf(c2, 1e-30f) : -1.0f;
+                } else {
+                    if (c1 > best) d1 = -1.0f;
+                    if (c2 > best) d2 = -1.0f;
+                }
                 if (slow) {
                     d1 = hitAABB(S, invdir, lAA, lBB);
                     d2 = hitAABB(S, invdir, rAA, rBB);
                 }
                 const int le = __float_as_int(q3.x), re = __float_as_int(q3.y);
                 bool popped = false;
-                if (d1 > 0.0f && d2 > 0.0f) {
+                if (ENTRY && phase == 1) {
+                    popped = true;  // (no descent: this lane climbs)
+                    if (verified) {
+                        op = OP_H;  // W at t_W is the reference's answer
+                    } else if (refuted) {
+                        phase = 2, sp = -1, op = OP_END;  // the reference never reaches W's leaf: its own walk decides (sp = -1: restart)
+                    }
+                } else if (d1 > 0.0f && d2 > 0.0f) {
                     if (d1 < d2) {  // left first
                         wstack_push<SPILL>(stk_lds, stk_spill, stk_stride, sp++, re);
                         cur = le;
@@ -711,7 +762,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 } else if (d2 > 0.0f) {
                     cur = re;
                 } else if (sp == 0) {
-                    op = OP_H;
+                    op = ENTRY ? OP_END : OP_H;
                     popped = true;
                 } else {
                     cur = wstack_pop<SPILL>(stk_lds, stk_spill, stk_stride, --sp);
@@ -739,24 +790,36 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             const int total = __shfl(incl, 63, 64);
             const int n_items = total < 64 ? total : 64;
             if (leaf) s_key[lane] = ~0ull;
+            if (ENTRY && leaf) s_tie[lane] = 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j)  // the reference builds leaves of up to 8 triangles (c5:843): no loop overhead for those
                 if (j < serve) s_item[start + j] = ((ti + j) << 6) | lane;
             for (int j = 8; __any(j < serve); ++j)
                 if (j < serve) s_item[start + j] = ((ti + j) << 6) | lane;
             __syncthreads();  // one wave per workgroup: a fence only
+            int my_owner = 0, my_tri = 0;
+            float my_t = -1.0f;  // < 0: this lane's item (if any) was not a hit
             if (lane < n_items) {
                 const int it = s_item[lane];
                 const int owner = it & 63, tri = it >> 6;
                 const float4 r0 = s_ray[2 * owner], r1 = s_ray[2 * owner + 1];
-                const float4 a = sc.ttri[tri * 3 + 0], b = sc.ttri[tri * 3 + 1], c = sc.ttri[tri * 3 + 2];
+                const float4* tb = (ENTRY && __float_as_int(r1.z) == 0) ? sc.ttri2 : sc.ttri;  // the owner's phase: which tree its leaf is of
+                const float4 a = tb[tri * 3 + 0], b = tb[tri * 3 + 1], c = tb[tri * 3 + 2];
                 float t;
                 const bool hit = hitTriangleT(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), v3(c.y, c.z, c.w),
                                               v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y), &t);
                 if (hit) atomicMin(&s_key[owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)tri);
                 if (STATS) s_t[lane] = hit ? t : INF_;
+                if (ENTRY && hit) my_owner = owner, my_tri = tri, my_t = t;
             }
             __syncthreads();
+            if (ENTRY) {  // two items of one owner at exactly its smallest distance: a tie the entry BVH's order must not decide
+                if (my_t >= 0.0f) {
+                    const unsigned long long k = s_key[my_owner];
+                    if (__uint_as_float((unsigned)(k >> 32)) == my_t && (int)(unsigned)k != my_tri) s_tie[my_owner] = 1;
+                }
+                __syncthreads();
+            }
             if (leaf && serve > 0) {
                 bool done = false;
                 if (STATS) {
@@ -769,7 +832,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 const unsigned long long key = s_key[lane];
                 if (key != ~0ull) {
                     const float t = __uint_as_float((unsigned)(key >> 32));
+                    if (ENTRY && phase == 0 && t == best && (int)(unsigned)key != best_tri) tie = true;
                     if (t < best) {
+                        if (ENTRY) tie = (phase == 0) && (s_tie[lane] != 0);
                         best = t;
                         best_tri = (int)(unsigned)key;
                         // an env-visibility ray only needs isHit (f5:869); statistics builds count the full walk
@@ -790,11 +855,31 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                         }
                     }
                 }
-                if (done) op = OP_H;
+                if (done) op = ENTRY ? OP_END : OP_H;
             }
             if (STATS && lane == 0) dg[10]++, dg[11] += n_items;
         }
-
+        // ---- a walk ended: the next phase of the same ray, or the ray is done ----------------------------------------------
+        if (ENTRY && op == OP_END) {
+            if (ENTRY && phase == 0 && best_tri >= 0 && !(tie && kind != K_SHADOW)) {
+                // the entry BVH's closest (env-visibility rays: first) acceptable hit W: climb from its reference leaf
+                const int w = sc.map2[best_tri];
+                best_tri = w, phase = 1, cur = sc.leafx[w], op = OP_INT;
+            } else if (ENTRY && (phase == 0 ? best_tri >= 0 : phase == 2 && sp < 0)) {
+                // (phase 0 with a tie, or a refuted check — marked by sp = -1 below —: the reference's own walk)
+                phase = 2;
+                best = INF_, best_tri = -1, sp = 0, cur = sc.root_entry;
+                s_ray[2 * lane + 1].z = __int_as_float(phase);
+                if (cur >= 0) {
+                    op = OP_INT;
+                } else {
+                    op = OP_LEAF, ti = cur & 0x00ffffff, leaf_best = INF_;
+                    if (STATS) st.leaves++;
+                }
+            } else {
+                op = OP_H;
+            }
+        }
 #ifdef RT_OP_CYCLES
         oc[oc_pick > 2 ? 2 : oc_pick] += (unsigned long long)(clock64() - oc_t0);
 #endif
@@ -964,8 +1049,15 @@ struct rt_scene {
     float* d_frame = nullptr;    // rt_render: device copy of the caller's host accumulation buffer
     size_t frame_bytes = 0;
     int cu_count = 0;
-    rt_tuning tuning{kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames};
+    rt_tuning tuning{kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames, 0};
     float cull_eps = 0.0f;       // scene part of the culling margin; +inf = the BVH / triangles do not allow culling
+    void* d_nodes2 = nullptr;    // entry BVH (device-private, see host_fastbvh.cpp): records, triangles in its leaf order
+    void* d_ttri2 = nullptr;
+    void* d_map2 = nullptr;      // entry-BVH triangle -> caller's index; where each reference leaf / node box lives (the climb)
+    void* d_leafx = nullptr;
+    void* d_parentx = nullptr;
+    bool has_entry = false;
+    float cost_ref = 0.0f, cost_entry = 0.0f;  // expected internal-node visits of a random line: reference tree, entry BVH
 };
 
 static int f2i_checked(float f, int* out) {
@@ -995,6 +1087,7 @@ void rt_scene_destroy(rt_scene* s) {
     (void)hipFree(s->d_frame);
     (void)hipFree(s->d_ttri), (void)hipFree(s->d_dmat), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
     (void)hipFree(s->d_cache), (void)hipFree(s->d_cdir), (void)hipFree(s->d_spill), (void)hipFree(s->d_clk);
+    (void)hipFree(s->d_nodes2), (void)hipFree(s->d_ttri2), (void)hipFree(s->d_map2), (void)hipFree(s->d_leafx), (void)hipFree(s->d_parentx);
     for (auto& sl : s->slot) {
         (void)hipFree(sl.d_spill), (void)hipFree(sl.d_samples), (void)hipFree(sl.d_queue), (void)hipFree(sl.d_sobol);
         if (sl.render_done) (void)hipEventDestroy(sl.render_done);
@@ -1006,6 +1099,12 @@ void rt_scene_destroy(rt_scene* s) {
 
 int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const float* hdr_map, const float* hdr_cache,
                     int hdrW, int hdrH, rt_scene** out) {
+    return rt_scene_create_ex(tris, nT, nodes, nN, hdr_map, hdr_cache, hdrW, hdrH, nullptr, out);
+}
+
+int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, const float* hdr_map, const float* hdr_cache,
+                       int hdrW, int hdrH, const rt_scene_options* opt, rt_scene** out) {
+    const int entry_mode = opt ? opt->entry_bvh : 0;
     if (!out) return set_error(RT_ERR_INVALID_ARG, "rt_scene_create: out is NULL");
     *out = nullptr;
     if (nT < 0 || nN < 0 || (nT > 0 && !tris) || (nN > 0 && !nodes))
@@ -1108,10 +1207,10 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     double cull_extent = 0.0;
     float cull_geo_max = 0.0f;
     bool cull_ok = has_root;
+    std::vector<float> tri_margin(nT > 0 ? nT : 0, -1.0f);  // -1: not acceptable
     {
         const float inf = __builtin_inff();
         auto fin = [inf](float v) { return fabsf(v) < inf; };
-        std::vector<float> tri_margin(nT > 0 ? nT : 0, -1.0f);  // -1: not acceptable
         for (int i = 0; i < nT; ++i) {
             const float* q = &ttri[(size_t)i * 12];
             bool ok = true;
@@ -1174,11 +1273,115 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     float cull_eps = __builtin_inff();
     if (cull_ok && cull_extent > 1e-10 && cull_extent < 1e30) cull_eps = nextafterf((float)(cull_extent / 8192.0), __builtin_inff());  // 2^-13 * extent
 
+    // ---- entry BVH (host_fastbvh.cpp): only where the reference tree is expensive to walk ---------------------------------
+    // Expected internal nodes a random line through the root box visits = sum over internal nodes of area / root area.
+    // The reference's INF = 114514 median splits (c5:500-502) push that into the hundreds on large scenes; a binned-SAH tree
+    // over the same triangles stays in the tens.  The path loop then walks the entry BVH first (conservative box test, real
+    // triangle test) to get a distance bound or to prove there is nothing to hit, and the reference tree only inside that
+    // bound (rt_device.hip, "phase").  Built when the reference tree costs > 32 and kept when at least twice as cheap.
+    std::vector<float> rec2, ttri2;
+    std::vector<int> map2, leafx, parentx;
+    int root_entry2 = 0, depth2 = 0;
+    double cost_ref = 0.0, cost_entry = 0.0;
+    bool has_entry = false;
+    if (cull_eps < __builtin_inff() && !order.empty() && entry_mode >= 0 && (nT >= 1024 || entry_mode > 0)) {
+        auto area = [](const float* lo, const float* hi) {
+            const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+            return (x < 0 || y < 0 || z < 0) ? 0.0 : 2.0 * (x * y + x * z + y * z);
+        };
+        const double root_area = area(&N[1].AA.x, &N[1].BB.x);
+        for (size_t k = 0; k < order.size(); ++k) cost_ref += area(&N[order[k]].AA.x, &N[order[k]].BB.x);
+        cost_ref = root_area > 0.0 ? cost_ref / root_area : 0.0;
+        if (cost_ref > 32.0 || entry_mode > 0) {
+            std::vector<float> tb((size_t)nT * 6);
+            std::vector<char> use(nT, 0);
+            for (int i = 0; i < nT; ++i) {
+                if (tri_margin[i] < 0.0f) continue;  // can never be hit
+                use[i] = 1;
+                const float* q = &ttri[(size_t)i * 12];
+                for (int c = 0; c < 3; ++c) {
+                    tb[(size_t)i * 6 + c] = fminf(q[c], fminf(q[3 + c], q[6 + c]));
+                    tb[(size_t)i * 6 + 3 + c] = fmaxf(q[c], fmaxf(q[3 + c], q[6 + c]));
+                }
+            }
+            std::vector<FastBvhNode> fn;
+            std::vector<int> perm;
+            const int root = build_fast_bvh(tb.data(), use.data(), nT, fn, perm);
+            if (root >= 0 && fn[root].count == 0) {
+                // records in pre-order (same 64-B layout as the reference tree's), triangles in leaf order
+                std::vector<int> rec_of2(fn.size(), -1), order2;
+                std::vector<std::pair<int, int>> stack2;
+                stack2.push_back({root, 0});
+                while (!stack2.empty()) {
+                    const int id = stack2.back().first, dep = stack2.back().second;
+                    stack2.pop_back();
+                    if (dep > depth2) depth2 = dep;
+                    if (fn[id].count > 0) continue;
+                    rec_of2[id] = (int)order2.size();
+                    order2.push_back(id);
+                    stack2.push_back({fn[id].right, dep + 1});
+                    stack2.push_back({fn[id].left, dep + 1});
+                }
+                const double ra2 = area(fn[root].AA, fn[root].BB);
+                for (int id : order2) cost_entry += area(fn[id].AA, fn[id].BB);
+                cost_entry = ra2 > 0.0 ? cost_entry / ra2 : 0.0;
+                if ((cost_entry * 2.0 < cost_ref || entry_mode > 0) && depth2 + 1 <= kMaxStack) {
+                    ttri2.resize(perm.size() * 12);
+                    for (size_t k = 0; k < perm.size(); ++k) memcpy(&ttri2[k * 12], &ttri[(size_t)perm[k] * 12], 48);
+                    rec2.assign(order2.size() * 16, 0.0f);
+                    std::vector<float> margin2(fn.size(), 0.0f);
+                    for (size_t k = order2.size(); k-- > 0;) {  // children come after their parent: walk backwards
+                        const FastBvhNode& nd = fn[order2[k]];
+                        const int ch[2] = {nd.left, nd.right};
+                        float m = 0.0f;
+                        float* q = &rec2[k * 16];
+                        for (int c = 0; c < 2; ++c) {
+                            const FastBvhNode& cn = fn[ch[c]];
+                            memcpy(q + 6 * c, cn.AA, 12), memcpy(q + 6 * c + 3, cn.BB, 12);
+                            int e;
+                            if (cn.count > 0) {
+                                float lm = 0.0f;
+                                for (int i = cn.first; i < cn.first + cn.count; ++i) lm = fmaxf(lm, tri_margin[perm[i]]);
+                                margin2[ch[c]] = lm;
+                                e = pack_leaf(cn.first, cn.count);
+                            } else {
+                                e = rec_of2[ch[c]];
+                            }
+                            memcpy(q + 12 + c, &e, 4);
+                            memcpy(q + 14 + c, &margin2[ch[c]], 4);
+                            m = fmaxf(m, margin2[ch[c]]);
+                        }
+                        margin2[order2[k]] = m;
+                    }
+                    root_entry2 = 0;  // record 0 = the root (pre-order)
+                    has_entry = true;
+                    map2 = perm;
+                    // where each reference box lives, for the climb from a triangle's leaf to the root (phase 1)
+                    leafx.assign(nT, -1), parentx.assign(order.size(), -1);
+                    for (size_t k = 0; k < order.size(); ++k) {
+                        const NodeRec& nd = N[order[k]];
+                        const int ch[2] = {(int)nd.left, (int)nd.right};
+                        for (int c = 0; c < 2; ++c) {
+                            const NodeRec& cn = N[ch[c]];
+                            const int x = (int)(k << 1) | c;
+                            if (cn.n > 0.0f) {
+                                for (int i = (int)cn.index; i < (int)cn.index + (int)cn.n; ++i) leafx[i] = x;
+                            } else {
+                                parentx[rec_of[ch[c]]] = x;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
     rt_scene* s = new rt_scene();
     s->device = g_device;
     s->cull_eps = cull_eps;
     s->dev.cull_geo_max = cull_geo_max;
-    s->nT = nT, s->nN = nN, s->max_stack = need_stack;
+    s->nT = nT, s->nN = nN, s->max_stack = has_entry && depth2 + 1 > need_stack ? depth2 + 1 : need_stack;
+    s->cost_ref = (float)cost_ref, s->cost_entry = (float)cost_entry, s->has_entry = has_entry;
     auto fail = [&](int rc) {
         rt_scene_destroy(s);
         return rc;
@@ -1212,6 +1415,18 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
         HIPCHK_S(hipMalloc(&s->d_nodes, rec.size() * 4));
         HIPCHK_S(hipMemcpy(s->d_nodes, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
     }
+    if (has_entry) {
+        HIPCHK_S(hipMalloc(&s->d_nodes2, rec2.size() * 4));
+        HIPCHK_S(hipMemcpy(s->d_nodes2, rec2.data(), rec2.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK_S(hipMalloc(&s->d_ttri2, ttri2.size() * 4));
+        HIPCHK_S(hipMemcpy(s->d_ttri2, ttri2.data(), ttri2.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK_S(hipMalloc(&s->d_map2, map2.size() * 4));
+        HIPCHK_S(hipMemcpy(s->d_map2, map2.data(), map2.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK_S(hipMalloc(&s->d_leafx, leafx.size() * 4));
+        HIPCHK_S(hipMemcpy(s->d_leafx, leafx.data(), leafx.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK_S(hipMalloc(&s->d_parentx, parentx.size() * 4));
+        HIPCHK_S(hipMemcpy(s->d_parentx, parentx.data(), parentx.size() * 4, hipMemcpyHostToDevice));
+    }
     const size_t npx = (size_t)(hdr_map ? hdrW : 0) * (size_t)(hdr_map ? hdrH : 0);
     if (hdr_map) {
         std::vector<float> tmp(npx * 4, 0.0f);
@@ -1242,6 +1457,11 @@ int rt_scene_create(const float* tris, int nT, const float* nodes, int nN, const
     s->dev.has_root = has_root ? 1 : 0;
     s->dev.root_entry = has_root ? entry[1] : 0;
     s->dev.cull_eps = cull_eps;
+    s->dev.nodes2 = (const float4*)s->d_nodes2;
+    s->dev.ttri2 = (const float4*)s->d_ttri2;
+    s->dev.map2 = (const int*)s->d_map2, s->dev.leafx = (const int*)s->d_leafx, s->dev.parentx = (const int*)s->d_parentx;
+    s->dev.root_entry2 = root_entry2;
+    s->dev.has_entry = has_entry ? 1 : 0;
     *out = s;
     return RT_OK;
 }
@@ -1345,6 +1565,8 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
     const int blocks = render_blocks(s);
     const int launch_frames = ws.launch_frames;
     const bool spill = ws.slot[0].spill != nullptr;
+    // the instantiation that knows the entry BVH: not for the reference-walk statistics (they never leave the reference tree)
+    const bool entry = P.sc.has_entry != 0 && (!STATS || stats_executed != 0);
     const int n_tiles = ((d->width + 7) / 8) * ((d->height + 7) / 8);
     const int fold_blocks = (int)(((size_t)d->width * d->height + 255) / 256);
     for (int done = 0; done < frame_count; done += launch_frames) {
@@ -1369,12 +1591,19 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
             HIPCHK(hipEventCreate(&tl.b));
             HIPCHK(hipEventRecord(tl.a, rstream));
         }
-#define LAUNCH(MODE_)                                                                                 \
-    do {                                                                                              \
-        if (spill)                                                                                    \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, true>), dim3(grid), dim3(kWave), 0, rstream, P);  \
-        else                                                                                          \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, false>), dim3(grid), dim3(kWave), 0, rstream, P); \
+#define LAUNCH2(MODE_, SPILL_)                                                                                  \
+    do {                                                                                                        \
+        if (entry)                                                                                              \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, SPILL_, true>), dim3(grid), dim3(kWave), 0, rstream, P);  \
+        else                                                                                                    \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, SPILL_, false>), dim3(grid), dim3(kWave), 0, rstream, P); \
+    } while (0)
+#define LAUNCH(MODE_)                  \
+    do {                               \
+        if (spill)                     \
+            LAUNCH2(MODE_, true);      \
+        else                           \
+            LAUNCH2(MODE_, false);     \
     } while (0)
         if (d->mode == RT_MODE_CHAP5)
             LAUNCH(RT_MODE_CHAP5);
@@ -1383,6 +1612,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         else
             LAUNCH(RT_MODE_CHAP3);
 #undef LAUNCH
+#undef LAUNCH2
         HIPCHK(hipGetLastError());
         if (timed) {
             HIPCHK(hipEventRecord(tl.b, rstream));
@@ -1497,7 +1727,7 @@ int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out) {
 
 int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     if (!s) return set_error(RT_ERR_INVALID_ARG, "rt_scene_set_tuning: NULL scene");
-    const rt_tuning def = {kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames};
+    const rt_tuning def = {kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames, 0};
     rt_tuning n = t ? *t : def;
     if (n.launch_frames <= 0) n.launch_frames = def.launch_frames;
     if (n.unit_frames <= 0) n.unit_frames = def.unit_frames;
@@ -1512,6 +1742,9 @@ int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     if (n.overlap_frames <= 0) n.overlap_frames = def.overlap_frames;
     s->tuning = n;
     s->dev.cull_eps = n.no_cull ? __builtin_inff() : s->cull_eps;
+    n.no_entry_bvh = n.no_entry_bvh > 0 ? 1 : 0;
+    s->tuning = n;
+    s->dev.has_entry = (s->has_entry && !n.no_entry_bvh && !n.no_cull) ? 1 : 0;
     return RT_OK;
 }
 
@@ -1523,6 +1756,8 @@ int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
     out->cull_enabled = (s->dev.cull_eps < __builtin_inff()) ? 1 : 0;
     out->cull_eps = s->cull_eps;
     out->device = s->device;
+    out->entry_bvh = s->dev.has_entry;
+    out->cost_reference_tree = s->cost_ref, out->cost_entry_bvh = s->cost_entry;
     return RT_OK;
 }
 

@@ -28,6 +28,14 @@ static_assert(sizeof(NodeRec) == 48, "BVHNode_encoded is 48 bytes");
 
 int set_error(int code, const char* fmt, ...);
 
+// host_fastbvh.cpp: the device-private entry BVH (binned SAH) over the same triangles; never visible at the ABI
+struct FastBvhNode {
+    float AA[3], BB[3];
+    int left, right;   // internal node: children (indices into the node array)
+    int first, count;  // leaf (count > 0): triangles order[first .. first + count)
+};
+int build_fast_bvh(const float* tri_box, const char* use, int n_tri, std::vector<FastBvhNode>& nodes, std::vector<int>& order);
+
 struct mat4 {
     float c[4][4];  // c[col][row], column-major like GLM
 };

@@ -34,16 +34,30 @@ RT_HD float hitAABB(vec3 S, vec3 invdir, vec3 AA, vec3 BB) {
 // results are only compared, so the sign of a zero does not matter); rays that can produce NaN (a zero/NaN direction
 // component or a non-finite origin) take the exact form instead (`slow`) and are never culled.
 constexpr float kCullRel = 1.0f / 8192.0f;  // 2^-13
-RT_HD float hitAABB_cull(vec3 S, vec3 invdir, vec3 AA, vec3 BB, float eps_ray, float eps_box, float* t0c) {
+// t1c (optional) is the matching conservative EXIT distance, min_i ( max(n_i, f_i) + eps * |invdir_i| ): by the same
+// argument t <= t1c for every accepted hit below the box.  The entry BVH (a device-private tree that only supplies a
+// distance bound, see rt_device.hip) is walked with the conservative test alone: a box may hold an acceptable hit closer
+// than `best` only if t0c <= t1c, t1c >= 0 and t0c <= best.
+RT_HD float hitAABB_cull(vec3 S, vec3 invdir, vec3 AA, vec3 BB, float eps_ray, float eps_box, float* t0c, float* t1c = nullptr) {
     const float eps = eps_ray + eps_box;
     const vec3 f = (BB - S) * invdir;
     const vec3 n = (AA - S) * invdir;
     const float mx = __builtin_fminf(f.x, n.x), my = __builtin_fminf(f.y, n.y), mz = __builtin_fminf(f.z, n.z);
-    const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fmaxf(f.y, n.y)), __builtin_fmaxf(f.z, n.z));
+    const float Mx = __builtin_fmaxf(f.x, n.x), My = __builtin_fmaxf(f.y, n.y), Mz = __builtin_fmaxf(f.z, n.z);
+    const float t1 = __builtin_fminf(__builtin_fminf(Mx, My), Mz);
     const float t0 = __builtin_fmaxf(__builtin_fmaxf(mx, my), mz);
-    *t0c = __builtin_fmaxf(__builtin_fmaxf(mx - eps * __builtin_fabsf(invdir.x), my - eps * __builtin_fabsf(invdir.y)),
-                           mz - eps * __builtin_fabsf(invdir.z));
+    const float ex = eps * __builtin_fabsf(invdir.x), ey = eps * __builtin_fabsf(invdir.y), ez = eps * __builtin_fabsf(invdir.z);
+    *t0c = __builtin_fmaxf(__builtin_fmaxf(mx - ex, my - ey), mz - ez);
+    if (t1c) *t1c = __builtin_fminf(__builtin_fminf(Mx + ex, My + ey), Mz + ez);
     return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+}
+// The entry BVH's box test: > 0 (a key to order the two children, near first) when the box may hold an acceptable hit
+// closer than `best`, else -1.
+RT_HD float hitAABB_entry(vec3 S, vec3 invdir, vec3 AA, vec3 BB, float eps_ray, float eps_box, float best) {
+    float t0c, t1c;
+    (void)hitAABB_cull(S, invdir, AA, BB, eps_ray, eps_box, &t0c, &t1c);
+    const bool may = (t0c <= t1c) && (t1c >= 0.0f) && (t0c <= best);
+    return may ? __builtin_fmaxf(t0c, 1e-30f) : -1.0f;
 }
 // the culling margin of a ray (+inf: never cull): `slow` rays (NaN-exact box test) and rays whose margin could overflow
 RT_HD float cull_margin(float scene_eps, float geo_max, vec3 S, vec3 invdir, bool slow) {

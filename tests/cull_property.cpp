@@ -111,12 +111,13 @@ int main(int argc, char** argv) {
         // ---- boxes that contain the triangle: the tight one and randomly grown ones (ancestors) ----
         vec3 AA = min3(p1, min3(p2, p3)), BB = max3(p1, max3(p2, p3));
         for (int rep = 0; rep < 4; ++rep) {
-            float t0c;
-            (void)hitAABB_cull(S, invdir, AA, BB, eps_ray, eps_box, &t0c);
+            float t0c, t1c;
+            (void)hitAABB_cull(S, invdir, AA, BB, eps_ray, eps_box, &t0c, &t1c);
             ++checked;
-            if (!(t0c <= t)) {
+            // the entry BVH's conservative test must let this box through for any best >= t
+            if (!(t0c <= t) || !(t <= t1c) || !(hitAABB_entry(S, invdir, AA, BB, eps_ray, eps_box, t) > 0.0f)) {
                 if (++violations <= 10)
-                    fprintf(stderr, "VIOLATION kind %d: t0c %.9g > t %.9g  S (%g %g %g) d (%g %g %g) eps %g + %g\n", kind, t0c, t, S.x, S.y, S.z, d.x, d.y, d.z, eps_ray, eps_box);
+                    fprintf(stderr, "VIOLATION kind %d: t0c %.9g <= t %.9g <= t1c fails  S (%g %g %g) d (%g %g %g) eps %g + %g\n", kind, t0c, t, S.x, S.y, S.z, d.x, d.y, d.z, eps_ray, eps_box);
             }
             // the margin this hit needed on the binding axis, as a fraction of the margin provided
             const float inv[3] = {invdir.x, invdir.y, invdir.z}, a[3] = {AA.x, AA.y, AA.z}, b[3] = {BB.x, BB.y, BB.z}, s[3] = {S.x, S.y, S.z};

@@ -62,11 +62,15 @@ def test_primary_hits_rotated_camera(scene_chap5):
     assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
 
 
+@pytest.mark.parametrize("entry", [0, 1])
 @pytest.mark.parametrize("mode", [3, 4, 5])
-def test_render_small_scene_bit_exact(scene_small, hdr_pair, mode):
+def test_render_small_scene_bit_exact(scene_small, hdr_pair, mode, entry):
+    """entry = 1 forces the device-private entry BVH (rt_scene_options.entry_bvh): every ray is then answered by the entry walk +
+    the climb through the reference tree's boxes, or falls back to the reference's own walk — same image, same statistics."""
     tris, nodes = scene_small
     hdr, cache = hdr_pair
-    sc = rt.Scene(tris, nodes, hdr, cache)
+    sc = rt.Scene(tris, nodes, hdr, cache, entry_bvh=entry)
+    assert sc.info().entry_bvh == entry
     eye, cam = rt.camera(20.0, 15.0, 3.5)
     W, H, F = 96, 80, 6
     d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam)
@@ -306,13 +310,17 @@ def test_config4_full_resolution_bit_exact(scene_chap4, hdr_pair):
     assert sc.render_stats(d, 0, F) == ost
 
 
-def test_synthetic_scene_small_instance_bit_exact(hdr_pair):
+@pytest.mark.parametrize("entry", [0, 1])
+def test_synthetic_scene_small_instance_bit_exact(hdr_pair, entry):
     """The generator of the 10 M-triangle 'synthetic' config at a size the oracle finishes in seconds (many objects,
     mixed materials, INF-quirk median splits near the root)."""
     from ray_tracing_amd import scenes
     tris, nodes = scenes.synthetic_scene(25, 12)
     hdr, cache = hdr_pair
-    sc = rt.Scene(tris, nodes, hdr, cache)
+    sc = rt.Scene(tris, nodes, hdr, cache, entry_bvh=entry)
+    i = sc.info()  # the INF-quirk tree is expensive to walk (cost > 32); entry = 0: the library keeps the entry BVH only if twice as cheap
+    assert i.cost_reference_tree > 32
+    assert i.entry_bvh == (1 if entry else int(0 < i.cost_entry_bvh * 2 < i.cost_reference_tree))
     eye, cam = rt.camera(15.0, 25.0, 6.0)
     W, H, F = 200, 120, 3
     d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
@@ -382,12 +390,14 @@ def _duplicated_scene(copies=3, leaf=2):
     return mesh.triangles(), nodes
 
 
-def test_tie_rules_on_exactly_duplicated_geometry(hdr_pair):
+@pytest.mark.parametrize("entry", [0, 1])
+def test_tie_rules_on_exactly_duplicated_geometry(hdr_pair, entry):
     """hitArray keeps the lowest index inside a leaf, hitBVH the first leaf visited (strict <, f5:250, 278); chapter 2 keeps the
     right-most leaf (c2:512).  With every triangle present three times all of that decides the picture."""
     tris, nodes = _duplicated_scene()
     hdr, cache = hdr_pair
-    sc = rt.Scene(tris, nodes, hdr, cache)
+    sc = rt.Scene(tris, nodes, hdr, cache, entry_bvh=entry)  # entry = 1: every hit is a tie, so every hit ray must fall back
+    assert sc.info().entry_bvh == entry
     eye, cam = rt.camera(25.0, 20.0, 3.5)
     W, H, F = 112, 80, 4
     for mode in (5, 4):
@@ -402,12 +412,13 @@ def test_tie_rules_on_exactly_duplicated_geometry(hdr_pair):
     assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
 
 
-def test_axis_aligned_and_non_finite_rays(scene_small, hdr_pair):
+@pytest.mark.parametrize("entry", [0, 1])
+def test_axis_aligned_and_non_finite_rays(scene_small, hdr_pair, entry):
     """Rays with zero direction components (1/0 = inf in hitAABB, f5:226) and a non-finite eye take the exact ternary box test:
     an odd image size puts a pixel centre exactly on the optical axis; the images must still equal the oracle's, NaNs included."""
     tris, nodes = scene_small
     hdr, cache = hdr_pair
-    sc = rt.Scene(tris, nodes, hdr, cache)
+    sc = rt.Scene(tris, nodes, hdr, cache, entry_bvh=entry)
     W = H = 65
     ident = np.eye(4, dtype=np.float32).reshape(16)
     d = rt.make_desc(W, H, eye=(0.1, 0.6, 4.0), camera_rotate=ident)
@@ -449,13 +460,14 @@ def _random_soup(seed):
     return mesh.triangles(), nodes, rng
 
 
+@pytest.mark.parametrize("entry", [0, 1])
 @pytest.mark.parametrize("seed", range(6))
-def test_random_triangle_soups(hdr_pair, seed):
+def test_random_triangle_soups(hdr_pair, seed, entry):
     """Random soups with random vertex normals and materials (extremes and degenerate triangles included), SAH and median
     BVHs with several leaf sizes, cameras inside the geometry: image, statistics and closest hits equal the oracle's."""
     tris, nodes, rng = _random_soup(seed)
     hdr, cache = hdr_pair
-    sc = rt.Scene(tris, nodes, hdr, cache)
+    sc = rt.Scene(tris, nodes, hdr, cache, entry_bvh=entry)
     eye, cam = rt.camera(float(rng.uniform(0, 360)), float(rng.uniform(-60, 60)), float(rng.uniform(0.2, 3.0)))
     W, H, F = int(rng.randint(20, 90)), int(rng.randint(20, 70)), 3
     for mode in (5, 4, 3):
@@ -526,9 +538,13 @@ def test_synthetic_10m_window_bit_exact_with_stats(scene_synth10m, hdr_pair):
     st = sc.render_stats(d, 0, F)
     assert st == ost, (st, ost)
     assert ost["internal_nodes"] / ost["rays"] > 300
-    assert sc.info().cull_enabled == 1 and sc.info().stack_spill == 1
-    ex = sc.render_stats(d, 0, F, executed=True)  # the walk the timed kernel executes: culled, a subset of the reference's
-    assert ex["rays"] == ost["rays"] and ex["internal_nodes"] < 0.5 * ost["internal_nodes"]
+    assert sc.info().cull_enabled == 1 and sc.info().stack_spill == 1 and sc.info().entry_bvh == 1
+    ex = sc.render_stats(d, 0, F, executed=True)  # the walk the timed kernel executes: entry BVH + climb, culled
+    assert ex["rays"] == ost["rays"] and ex["internal_nodes"] < 0.1 * ost["internal_nodes"]
+    sc.set_tuning(no_entry_bvh=1)                  # the culled reference walk alone: same image, more nodes
+    _assert_images_equal(sc.render(d, 0, F), ref, "synthetic 10M window, no entry BVH")
+    ex2 = sc.render_stats(d, 0, F, executed=True)
+    assert ex["internal_nodes"] < ex2["internal_nodes"] < 0.5 * ost["internal_nodes"]
     tri, dist = sc.primary_hits(rt.make_desc(W, H, eye=eye, camera_rotate=cam))
     otri, odist = O.primary_hits(tris, nodes, W, H, eye, cam)
     assert (tri >= 0).mean() > 0.5
@@ -603,16 +619,17 @@ def _sliver_soup(seed, scale=1.0, offset=0.0):
     return mesh.triangles(), nodes, rng
 
 
+@pytest.mark.parametrize("entry", [0, 1])
 @pytest.mark.parametrize("seed,scale,offset", [(0, 1.0, 0.0), (1, 1.0, 0.0), (2, 1e-3, 0.0), (3, 1.0, 900.0), (4, 250.0, 0.0), (5, 1.0, -37.5)])
-def test_culling_keeps_results_on_needles_slivers_and_flat_boxes(hdr_pair, seed, scale, offset):
+def test_culling_keeps_results_on_needles_slivers_and_flat_boxes(hdr_pair, seed, scale, offset, entry):
     """The product kernels skip subtrees whose inflated box starts beyond the closest hit (hitAABB_cull); the oracle, like the
     reference, walks everything.  Needles, ulp-thin slivers, flat boxes, ties, tiny / huge / far-off-origin coordinates and
     cameras inside, near and far: closest hits, images and the reference-walk statistics must not change, and the executed
     walk must be a subset of the reference's."""
     tris, nodes, rng = _sliver_soup(seed, scale, offset)
     hdr, cache = hdr_pair
-    sc = rt.Scene(tris, nodes, hdr, cache)
-    assert sc.info().cull_enabled == 1
+    sc = rt.Scene(tris, nodes, hdr, cache, entry_bvh=entry)  # entry = 1: the entry walk + climb answers (or hands over) every ray
+    assert sc.info().cull_enabled == 1 and sc.info().entry_bvh == entry
     ctr = np.array([offset] * 3, np.float32)
     for r in (0.3 * scale, 2.5 * scale, 40.0 * scale):
         eye, cam = rt.camera(float(rng.uniform(0, 360)), float(rng.uniform(-70, 70)), float(r))
@@ -628,12 +645,17 @@ def test_culling_keeps_results_on_needles_slivers_and_flat_boxes(hdr_pair, seed,
         assert sc.render_stats(d, 1, 2) == ost
         ex = sc.render_stats(d, 1, 2, executed=True)
         assert ex["rays"] == ost["rays"] and ex["paths"] == ost["paths"]
-        assert all(ex[k] <= ost[k] for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"))
+        if not entry:  # (the entry walk adds its own nodes: only on expensive trees is its total smaller)
+            assert all(ex[k] <= ost[k] for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"))
     # the same images with culling switched off through rt_tuning
     sc.set_tuning(no_cull=1)
-    assert sc.info().cull_enabled == 0
+    assert sc.info().cull_enabled == 0 and sc.info().entry_bvh == 0
     _assert_images_equal(sc.render(d, 1, 2), ref, "no_cull")
-    assert sc.render_stats(d, 1, 2, executed=True)["internal_nodes"] >= ex["internal_nodes"]
+    if not entry:
+        assert sc.render_stats(d, 1, 2, executed=True)["internal_nodes"] >= ex["internal_nodes"]
+    sc.set_tuning(no_cull=0, no_entry_bvh=1)
+    assert sc.info().cull_enabled == 1 and sc.info().entry_bvh == 0
+    _assert_images_equal(sc.render(d, 1, 2), ref, "no_entry_bvh")
 
 
 def test_culling_is_off_for_boxes_that_do_not_nest(scene_small, hdr_pair):
@@ -661,6 +683,7 @@ def test_culling_is_on_for_the_bundled_scenes(scene_chap2, scene_chap4, scene_ch
     for tris, nodes in (scene_chap2, scene_chap4, scene_chap5):
         i = rt.Scene(tris, nodes).info()
         assert i.cull_enabled == 1 and 0.0 < i.cull_eps < 1e-2
+        assert i.entry_bvh == 0 and i.cost_reference_tree < 32  # their trees are cheap to walk: no entry BVH
 
 
 # ---- viewer semantics in the C ABI ----------------------------------------------------------------------------
