@@ -169,6 +169,15 @@ int rt_primary_hits(rt_scene* s, const rt_render_desc* d, int32_t* tri_index_hos
 int rt_primary_hits_device(rt_scene* s, const rt_render_desc* d, int32_t* tri_index_dev, float* distance_dev,
                            void* hip_stream);
 
+/* One process, several GPUs (the C-side form of the spp split of SURVEY 8e; no counterpart in the reference).
+ * scenes[k] are replicas of one scene, one per device (rt_init(k); rt_scene_create(...)).  Replica k renders frames
+ * [frame_begin + k*frames_each, +frames_each); all devices work at once; sum_host (W*H*3 fp32) += the sum of all
+ * n_scenes*frames_each samples per pixel, added in scene order.  Divide by the number of frames accumulated to get
+ * lastFrame (equal to the running mean up to fp32 summation order).  Multi-process callers use one process per GPU and
+ * one RCCL reduce instead (bench.py). */
+int rt_render_multi(rt_scene* const* scenes, int n_scenes, const rt_render_desc* d, int frame_begin, int frames_each,
+                    float* sum_host);
+
 /* rt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc).  No counterpart in the reference.  Same arguments, same result (bit-identical to rt_render_device),
  * but it calls no hipMalloc / hipFree / hipEventCreate or other allocating routine: the work-queue counters, the Sobol

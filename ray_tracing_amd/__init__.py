@@ -436,6 +436,19 @@ class Viewer:
                                                  os.fsencode(path_pattern) if path_pattern else None, C.c_void_p(stream)))
 
 
+_lib.rt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p]
+
+
+def render_multi(scenes, desc: RenderDesc, frame_begin: int, frames_each: int, sum_host: np.ndarray | None = None) -> np.ndarray:
+    """rt_render_multi: replicas of one scene (one per GPU) render disjoint frame ranges at once; returns / updates the SUM buffer."""
+    if sum_host is None:
+        sum_host = np.zeros((desc.height, desc.width, 3), np.float32)
+    assert sum_host.dtype == np.float32 and sum_host.flags.c_contiguous
+    arr = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    _check(_lib.rt_render_multi(arr, len(scenes), C.byref(desc), frame_begin, frames_each, sum_host.ctypes.data))
+    return sum_host
+
+
 def kernel_time_ms(reset: bool = True):
     """(average ms, launches) of this thread's path-loop kernel launches since the last reset (HIP events)."""
     ms, n = C.c_float(), C.c_int()

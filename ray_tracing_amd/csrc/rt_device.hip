@@ -1867,6 +1867,47 @@ static int render_stats_impl(rt_scene* s, const rt_render_desc* d, int frame_beg
     return RT_OK;
 }
 
+int rt_render_multi(rt_scene* const* scenes, int n_scenes, const rt_render_desc* d, int frame_begin, int frames_each, float* sum_host) {
+    // One process, several GPUs (SURVEY 8e with the ranks folded into one caller): scene k — a replica on its own device —
+    // renders frames [frame_begin + k * frames_each, + frames_each) into its own SUM buffer; all devices run at once (the
+    // launches are asynchronous), then the buffers are added into sum_host in scene order (deterministic fp32 order).
+    if (!scenes || n_scenes <= 0 || !d || !sum_host) return set_error(RT_ERR_INVALID_ARG, "rt_render_multi: bad arguments");
+    if (frames_each < 0 || frame_begin < 0) return set_error(RT_ERR_INVALID_ARG, "rt_render_multi: negative frame range");
+    rt_render_desc ds = *d;
+    ds.accumulate = RT_ACCUM_SUM;
+    const size_t n = (size_t)(d->width > 0 ? d->width : 0) * (size_t)(d->height > 0 ? d->height : 0) * 3;
+    const size_t bytes = n * sizeof(float);
+    for (int k = 0; k < n_scenes; ++k) {
+        rt_scene* s = scenes[k];
+        int rc = check_render_args(s, &ds, frame_begin, frames_each, sum_host);
+        if (rc != RT_OK) return rc;
+        for (int j = 0; j < k; ++j)
+            if (scenes[j] == s) return set_error(RT_ERR_INVALID_ARG, "rt_render_multi: scene %d appears twice (each replica owns one workspace)", k);
+    }
+    if (frames_each == 0) return RT_OK;
+    for (int k = 0; k < n_scenes; ++k) {  // enqueue everywhere first: the devices work concurrently
+        rt_scene* s = scenes[k];
+        GUARD_DEVICE(s);
+        if (bytes > s->frame_bytes) {
+            (void)hipFree(s->d_frame);
+            s->d_frame = nullptr, s->frame_bytes = 0;
+            HIPCHK(hipMalloc((void**)&s->d_frame, bytes));
+            s->frame_bytes = bytes;
+        }
+        HIPCHK(hipMemsetAsync(s->d_frame, 0, bytes, nullptr));
+        const int rc = rt_render_device(s, &ds, frame_begin + k * frames_each, frames_each, s->d_frame, nullptr);
+        if (rc != RT_OK) return rc;
+    }
+    std::vector<float> stage(n);
+    for (int k = 0; k < n_scenes; ++k) {  // the "reduce": in scene order
+        rt_scene* s = scenes[k];
+        GUARD_DEVICE(s);
+        HIPCHK(hipMemcpy(stage.data(), s->d_frame, bytes, hipMemcpyDeviceToHost));  // (synchronises with the default stream)
+        for (size_t i = 0; i < n; ++i) sum_host[i] += stage[i];
+    }
+    return RT_OK;
+}
+
 int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out) {
     return render_stats_impl(s, d, frame_begin, frame_count, out, 0);
 }
