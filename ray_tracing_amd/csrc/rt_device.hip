@@ -64,9 +64,8 @@ struct DevScene {
     const float4* ttri;   // 3 x float4 per triangle: (p1.xyz,p2.x) (p2.yz,p3.xy) (p3.z,N.xyz)
     const float* tris;    // Triangle_encoded[nT], the caller's layout
     const float4* nodes;  // 4 x float4 per internal node: (lAA,lBB.x) (lBB.yz,rAA.xy) (rAA.z,rBB) (lentry,rentry,lmargin,rmargin)
-    const float4* dmat;   // 4 x float4 per triangle: material-only terms of chapter 5's BRDF (MatPre), see rt_shade.h
-    const float4* hdr;    // hdrMap as RGBX
-    const float4* cache;  // hdrCache as RGBX
+    const float4* dmat;   // 6 x float4 per triangle: material-only terms of chapter 5's BRDF (MatPre, rt_shade.h) + its per-evaluation fields
+    const float4* hdr;    // hdrMap as RGB + the pdf channel of hdrCache at the same texel (hdrPdf reads both, f5:638-660)
     const float4* cdir;   // per hdrCache texel: the direction SampleHdr returns for it (f5:615-624), xyz-
     int hdrW, hdrH;
     int root_entry;       // packed entry of node 1
@@ -279,8 +278,9 @@ __device__ __forceinline__ Mat load_material(const DevScene& sc, int tri) {
     return m;
 }
 
+constexpr int kDmatVec = 6;  // float4s per triangle in `dmat`: MatPre (4) + the material fields chapter 5's BRDF reads per evaluation (2)
 __device__ __forceinline__ MatPre load_mat_pre(const DevScene& sc, int tri) {
-    const float4 a = sc.dmat[tri * 4 + 0], b = sc.dmat[tri * 4 + 1], c = sc.dmat[tri * 4 + 2], d = sc.dmat[tri * 4 + 3];
+    const float4 a = sc.dmat[tri * kDmatVec + 0], b = sc.dmat[tri * kDmatVec + 1], c = sc.dmat[tri * kDmatVec + 2], d = sc.dmat[tri * kDmatVec + 3];
     MatPre q;
     q.Cspec0 = v3(a.x, a.y, a.z), q.Csheen = v3(a.w, b.x, b.y);
     q.a2 = b.z, q.a2m1 = b.w;
@@ -290,33 +290,15 @@ __device__ __forceinline__ MatPre load_mat_pre(const DevScene& sc, int tri) {
 }
 // the material fields chapter 5's BRDF still reads per evaluation (the rest is in MatPre)
 __device__ __forceinline__ Mat load_material_eval5(const DevScene& sc, int tri) {
-    const float* T = sc.tris + (size_t)tri * 36 + 18;
+    const float4 e = sc.dmat[tri * kDmatVec + 4], f = sc.dmat[tri * kDmatVec + 5];  // two 16-B loads instead of eight dwords of Triangle_encoded
     Mat m;
     m.emissive = v3(0);
-    m.baseColor = v3(T[3], T[4], T[5]);
-    m.subsurface = T[6], m.metallic = T[7], m.specular = 0.0f;
-    m.specularTint = 0.0f, m.roughness = T[10], m.anisotropic = 0.0f;
-    m.sheen = T[12], m.sheenTint = 0.0f, m.clearcoat = T[14];
+    m.baseColor = v3(e.x, e.y, e.z);
+    m.subsurface = e.w, m.metallic = f.x, m.specular = 0.0f;
+    m.specularTint = 0.0f, m.roughness = f.y, m.anisotropic = 0.0f;
+    m.sheen = f.z, m.sheenTint = 0.0f, m.clearcoat = f.w;
     m.clearcoatGloss = 0.0f;
     return m;
-}
-
-// ---- E1: hdrColor / sampleHdr, f5:638-644, f4:159-165 --------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ vec3 envColor(const DevScene& sc, vec3 v) {
-    if (!sc.hdr) return v3(0);
-    float u, w;
-    toSphericalCoord(normalize(v), &u, &w);
-    const float4 c = sc.hdr[texel_index(w, sc.hdrH) * sc.hdrW + texel_index(u, sc.hdrW)];
-    vec3 color = v3(c.x, c.y, c.z);
-    if (MODE != RT_MODE_CHAP5) color = min3(color, v3(10));
-    return color;
-}
-__device__ __forceinline__ float envPdf(const DevScene& sc, vec3 L) {  // hdrPdf, f5:648-660
-    float u, w;
-    toSphericalCoord(normalize(L), &u, &w);
-    const float4 c = sc.cache[texel_index(w, sc.hdrH) * sc.hdrW + texel_index(u, sc.hdrW)];
-    return hdrPdfConvert(c.z, w, sc.hdrW);
 }
 
 __device__ __forceinline__ bool lane_pixel(const RenderParams& P, int* px, int* py) {
@@ -514,7 +496,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     const float4 c = sc.hdr[texel];
                     color = v3(c.x, c.y, c.z);
                     if (MODE != RT_MODE_CHAP5) color = min3(color, v3(10));  // f4:162
-                    if (MODE == RT_MODE_CHAP5 && !isA) pdf_light = hdrPdfConvert(sc.cache[texel].z, ew, sc.hdrW);  // hdrPdf, f5:648-660
+                    // hdrPdf, f5:648-660: the pdf channel of hdrCache at the same texel rides in the map's spare .w (one gather)
+                    if (MODE == RT_MODE_CHAP5 && !isA) pdf_light = hdrPdfConvert(c.w, ew, sc.hdrW);
                 }
             }
             // step 3: what each kind of ray adds
@@ -1026,7 +1009,6 @@ struct rt_scene {
     void* d_tris = nullptr;
     void* d_nodes = nullptr;
     void* d_hdr = nullptr;
-    void* d_cache = nullptr;
     void* d_cdir = nullptr;
     int* d_spill = nullptr;      // primary_kernel's global stack spill (deep trees)
     size_t spill_bytes = 0;
@@ -1086,7 +1068,7 @@ void rt_scene_destroy(rt_scene* s) {
     (void)hipDeviceSynchronize();  // launches may still be in flight on the internal streams
     (void)hipFree(s->d_frame);
     (void)hipFree(s->d_ttri), (void)hipFree(s->d_dmat), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
-    (void)hipFree(s->d_cache), (void)hipFree(s->d_cdir), (void)hipFree(s->d_spill), (void)hipFree(s->d_clk);
+    (void)hipFree(s->d_cdir), (void)hipFree(s->d_spill), (void)hipFree(s->d_clk);
     (void)hipFree(s->d_nodes2), (void)hipFree(s->d_ttri2), (void)hipFree(s->d_map2), (void)hipFree(s->d_leafx), (void)hipFree(s->d_parentx);
     for (auto& sl : s->slot) {
         (void)hipFree(sl.d_spill), (void)hipFree(sl.d_samples), (void)hipFree(sl.d_queue), (void)hipFree(sl.d_sobol);
@@ -1181,7 +1163,7 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
         q[0] = t.p1.x, q[1] = t.p1.y, q[2] = t.p1.z, q[3] = t.p2.x, q[4] = t.p2.y, q[5] = t.p2.z;
         q[6] = t.p3.x, q[7] = t.p3.y, q[8] = t.p3.z, q[9] = Nn.x, q[10] = Nn.y, q[11] = Nn.z;
     }
-    std::vector<float> dmat((size_t)nT * 16, 0.0f);
+    std::vector<float> dmat((size_t)nT * kDmatVec * 4, 0.0f);
     for (int i = 0; i < nT; ++i) {
         const rt_material& rm = ((const TriRec*)tris)[i].m;
         Mat m;
@@ -1192,7 +1174,9 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
         m.sheen = rm.sheen, m.sheenTint = rm.sheenTint, m.clearcoat = rm.clearcoat;
         m.clearcoatGloss = rm.clearcoatGloss;
         const MatPre p = mat_precompute(m);
-        float* q = &dmat[(size_t)i * 16];
+        float* q = &dmat[(size_t)i * kDmatVec * 4];
+        q[16] = rm.baseColor[0], q[17] = rm.baseColor[1], q[18] = rm.baseColor[2], q[19] = rm.subsurface;
+        q[20] = rm.metallic, q[21] = rm.roughness, q[22] = rm.sheen, q[23] = rm.clearcoat;
         q[0] = p.Cspec0.x, q[1] = p.Cspec0.y, q[2] = p.Cspec0.z, q[3] = p.Csheen.x, q[4] = p.Csheen.y, q[5] = p.Csheen.z;
         q[6] = p.a2, q[7] = p.a2m1, q[8] = p.g1_a, q[9] = p.g1_a2, q[10] = p.g1_a2m1, q[11] = p.g1_k;
         q[12] = p.p_d, q[13] = p.p_s, q[14] = p.p_c, q[15] = p.g1_lg;
@@ -1430,13 +1414,15 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
     const size_t npx = (size_t)(hdr_map ? hdrW : 0) * (size_t)(hdr_map ? hdrH : 0);
     if (hdr_map) {
         std::vector<float> tmp(npx * 4, 0.0f);
-        for (size_t i = 0; i < npx; ++i) tmp[i * 4] = hdr_map[i * 3], tmp[i * 4 + 1] = hdr_map[i * 3 + 1], tmp[i * 4 + 2] = hdr_map[i * 3 + 2];
+        for (size_t i = 0; i < npx; ++i) {
+            tmp[i * 4] = hdr_map[i * 3], tmp[i * 4 + 1] = hdr_map[i * 3 + 1], tmp[i * 4 + 2] = hdr_map[i * 3 + 2];
+            tmp[i * 4 + 3] = hdr_cache ? hdr_cache[i * 3 + 2] : 0.0f;  // hdrCache's pdf channel (f5:651) at the same texel
+        }
         HIPCHK_S(hipMalloc(&s->d_hdr, npx * 16));
         HIPCHK_S(hipMemcpy(s->d_hdr, tmp.data(), npx * 16, hipMemcpyHostToDevice));
         if (hdr_cache) {
-            for (size_t i = 0; i < npx; ++i) tmp[i * 4] = hdr_cache[i * 3], tmp[i * 4 + 1] = hdr_cache[i * 3 + 1], tmp[i * 4 + 2] = hdr_cache[i * 3 + 2];
-            HIPCHK_S(hipMalloc(&s->d_cache, npx * 16));
-            HIPCHK_S(hipMemcpy(s->d_cache, tmp.data(), npx * 16, hipMemcpyHostToDevice));
+            // hdrCache reaches the device in two derived forms: its pdf channel in hdr.w (above) and, per texel, the direction
+            // SampleHdr computes from its (x, y) channels (f5:615-624)
             for (size_t i = 0; i < npx; ++i) {
                 const vec3 L = hdrDirection(hdr_cache[i * 3], hdr_cache[i * 3 + 1]);
                 tmp[i * 4] = L.x, tmp[i * 4 + 1] = L.y, tmp[i * 4 + 2] = L.z;
@@ -1451,7 +1437,6 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
     s->dev.tris = (const float*)s->d_tris;
     s->dev.nodes = (const float4*)s->d_nodes;
     s->dev.hdr = (const float4*)s->d_hdr;
-    s->dev.cache = (const float4*)s->d_cache;
     s->dev.cdir = (const float4*)s->d_cdir;
     s->dev.hdrW = hdrW, s->dev.hdrH = hdrH;
     s->dev.has_root = has_root ? 1 : 0;
@@ -1541,7 +1526,7 @@ static int check_render_args(const rt_scene* s, const rt_render_desc* d, int fra
         return set_error(RT_ERR_INVALID_ARG, "rt_render: unknown mode %d", d->mode);
     if (d->accumulate != RT_ACCUM_RUNNING_MEAN && d->accumulate != RT_ACCUM_SUM)
         return set_error(RT_ERR_INVALID_ARG, "rt_render: unknown accumulate mode %d", d->accumulate);
-    if (d->mode == RT_MODE_CHAP5 && !s->d_cache)
+    if (d->mode == RT_MODE_CHAP5 && !s->d_cdir)
         return set_error(RT_ERR_INVALID_ARG, "rt_render: mode 5 needs hdr_map and hdr_cache in the scene");
     const int mb = d->max_bounce > 0 ? d->max_bounce : (d->mode == RT_MODE_CHAP5 ? 4 : 6);
     if (d->mode == RT_MODE_CHAP5 && mb > 4)  // sobolVec2(i, bounce) reads V[(2*bounce+1)*32 + j] of the 8-dimension table (f5:339, 883)

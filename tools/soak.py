@@ -11,7 +11,7 @@ rng = np.random.RandomState(12345)
 hdr, cache = scenes.hdr_and_cache()
 pool = [scenes.small_scene(), scenes.chap5_scene(), scenes.chap4_scene(), scenes.synthetic_scene(9, 10),
         (np.zeros((0, 36), np.float32), np.zeros((1, 12), np.float32))]
-objs = [rt.Scene(t, n, hdr, cache) for t, n in pool]
+objs = [rt.Scene(t, n, hdr, cache) for t, n in pool] + [rt.Scene(t, n, hdr, cache, entry_bvh=1) for t, n in pool[:4]]
 t0 = time.time(); k = 0; paths = 0
 while time.time() - t0 < budget:
     sc = objs[rng.randint(len(objs))]
@@ -20,7 +20,8 @@ while time.time() - t0 < budget:
     mode = int(rng.choice([3, 4, 5]))
     sc.set_tuning(launch_frames=rng.choice([1, 2, 5, 32, 64]), unit_frames=rng.choice([1, 2, 3, 8]),
                   shade_lanes=rng.choice([1, 16, 48, 64]), leaf_lanes=rng.choice([1, 8, 64]),
-                  wait_budget=rng.choice([1, 100, 4000, 10**8]))
+                  wait_budget=rng.choice([1, 100, 4000, 10**8]), overlap_frames=rng.choice([1, 8, 1025]),
+                  no_cull=rng.choice([0, 0, 1]), no_entry_bvh=rng.choice([0, 0, 1]))
     eye, cam = rt.camera(float(rng.uniform(0, 360)), float(rng.uniform(-89, 89)), float(rng.uniform(0.05, 8)))
     d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam, accumulate=int(rng.randint(2)))
     img = sc.render(d, int(rng.randint(0, 5000)), F)
