@@ -1380,10 +1380,17 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
     HIPCHK_S(hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, s->device));
     HIPCHK_S(hipMalloc((void**)&s->d_clk, 64));
     HIPCHK_S(hipMemset(s->d_clk, 0, 64));
+    // The two slots' streams get different priorities: the runtime keeps separate hardware-queue pools per priority, so the
+    // two can never be mapped onto one hardware queue (GPU_MAX_HW_QUEUES is 4 per process and streams share queues; two
+    // equal-priority streams that land on the same queue would run their kernels one after the other — observed when other
+    // scenes had created streams before).
+    int prio_least = 0, prio_greatest = 0;
+    HIPCHK_S(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    int slot_no = 0;
     for (auto& sl : s->slot) {
         HIPCHK_S(hipMalloc((void**)&sl.d_queue, 8 * 16 * sizeof(unsigned)));
         HIPCHK_S(hipMalloc((void**)&sl.d_sobol, (size_t)kMaxLaunchFrames * 4 * sizeof(float2)));
-        HIPCHK_S(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        HIPCHK_S(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, slot_no++ == 0 ? prio_least : prio_greatest));
         HIPCHK_S(hipEventCreateWithFlags(&sl.render_done, hipEventDisableTiming));
         HIPCHK_S(hipEventCreateWithFlags(&sl.fold_done, hipEventDisableTiming));
     }
