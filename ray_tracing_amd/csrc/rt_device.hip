@@ -75,7 +75,9 @@ struct DevScene {
     const float4* nodes2; // entry BVH: node records (same layout as `nodes`) ...
     const float4* ttri2;  // ... and its triangles (same layout as `ttri`), in its own leaf order
     const int* map2;      // entry-BVH triangle -> index in the caller's order
-    const int* leafx;     // per triangle (caller's order): where its leaf's box lives = (record << 1 | side)
+    const unsigned* leafx; // per triangle (caller's order): where its leaf's box lives = (record << 1 | side), 24 bits; bits 24..31: how
+                          // many boxes of the climb need an explicit check for rays whose margin is <= climb_eps (255 = all)
+    float climb_eps;      // the ray margin (hitAABB_cull's eps_ray) the short climbs were computed for
     const int* parentx;   // per record of `nodes`: where that node's own box lives = (parent record << 1 | side); -1 = root
     int root_entry2;
     int has_entry;        // walk the entry BVH first (phase 0), then check its answer against the reference tree (phase 1)
@@ -707,7 +709,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     const float dv = (cur & 1) ? d2 : d1;
                     if (dv > 0.0f) {
                         const int up = sc.parentx[rec];
-                        if (up < 0) verified = true; else cur = up;
+                        if (sp != 255) --sp;  // (sp is free during the climb: the explicit checks still to do)
+                        if (up < 0 || sp == 0) verified = true; else cur = up;
                     } else {
                         refuted = true;
                     }
@@ -728,7 +731,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 if (ENTRY && phase == 1) {
                     popped = true;  // (no descent: this lane climbs)
                     if (verified) {
-                        op = OP_H;  // W at t_W is the reference's answer
+                        op = OP_H, sp = 0;  // W at t_W is the reference's answer
                     } else if (refuted) {
                         phase = 2, sp = -1, op = OP_END;  // the reference never reaches W's leaf: its own walk decides (sp = -1: restart)
                     }
@@ -847,7 +850,16 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (ENTRY && phase == 0 && best_tri >= 0 && !(tie && kind != K_SHADOW)) {
                 // the entry BVH's closest (env-visibility rays: first) acceptable hit W: climb from its reference leaf
                 const int w = sc.map2[best_tri];
-                best_tri = w, phase = 1, cur = sc.leafx[w], op = OP_INT;
+                const unsigned lx = sc.leafx[w];
+                // boxes to check explicitly: above them W's triangle lies inside every box by more than the margin, so the
+                // reference's test cannot fail there ("short climb"); 255 = up to the root
+                const int steps = (ceps <= sc.climb_eps) ? (int)(lx >> 24) : 255;
+                best_tri = w;
+                if (steps == 0) {
+                    op = OP_H;
+                } else {
+                    phase = 1, cur = (int)(lx & 0x00ffffffu), sp = steps, op = OP_INT;
+                }
             } else if (ENTRY && (phase == 0 ? best_tri >= 0 : phase == 2 && sp < 0)) {
                 // (phase 0 with a tie, or a refuted check — marked by sp = -1 below —: the reference's own walk)
                 phase = 2;
@@ -1264,7 +1276,9 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
     // triangle test) to get a distance bound or to prove there is nothing to hit, and the reference tree only inside that
     // bound (rt_device.hip, "phase").  Built when the reference tree costs > 32 and kept when at least twice as cheap.
     std::vector<float> rec2, ttri2;
-    std::vector<int> map2, leafx, parentx;
+    std::vector<int> map2, parentx;
+    std::vector<unsigned> leafx;
+    float climb_eps = 0.0f;
     int root_entry2 = 0, depth2 = 0;
     double cost_ref = 0.0, cost_entry = 0.0;
     bool has_entry = false;
@@ -1341,7 +1355,7 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
                     has_entry = true;
                     map2 = perm;
                     // where each reference box lives, for the climb from a triangle's leaf to the root (phase 1)
-                    leafx.assign(nT, -1), parentx.assign(order.size(), -1);
+                    leafx.assign(nT, 0u), parentx.assign(order.size(), -1);
                     for (size_t k = 0; k < order.size(); ++k) {
                         const NodeRec& nd = N[order[k]];
                         const int ch[2] = {(int)nd.left, (int)nd.right};
@@ -1349,11 +1363,42 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
                             const NodeRec& cn = N[ch[c]];
                             const int x = (int)(k << 1) | c;
                             if (cn.n > 0.0f) {
-                                for (int i = (int)cn.index; i < (int)cn.index + (int)cn.n; ++i) leafx[i] = x;
+                                for (int i = (int)cn.index; i < (int)cn.index + (int)cn.n; ++i) leafx[i] = (unsigned)x;
                             } else {
                                 parentx[rec_of[ch[c]]] = x;
                             }
                         }
+                    }
+                    // Short climbs.  Boxes nest, so going up from a triangle's leaf the triangle sits deeper and deeper inside:
+                    // from some level on it lies inside the box by more than mu = climb_eps + its shape margin on all six
+                    // sides.  An accepted hit point is within a fraction of that margin of the triangle (culling lemma), so it
+                    // is interior by ~mu, the slab parameters bracket t_W by mu / |d_i| — three orders of magnitude more than
+                    // their rounding error — and the reference's hitAABB returns > 0 for certain.  Only the levels below need
+                    // the explicit check; their number goes into bits 24..31 of leafx.  Valid for rays whose margin eps_ray
+                    // <= climb_eps = 4 x the scene part (origins within 3 scene extents); other rays climb to the root.
+                    climb_eps = 4.0f * cull_eps;
+                    for (int i = 0; i < nT; ++i) {
+                        if (tri_margin[i] < 0.0f) continue;
+                        const float* q = &ttri[(size_t)i * 12];
+                        double lo[3], hi[3];
+                        for (int c = 0; c < 3; ++c) {
+                            lo[c] = fmin((double)q[c], fmin((double)q[3 + c], (double)q[6 + c]));
+                            hi[c] = fmax((double)q[c], fmax((double)q[3 + c], (double)q[6 + c]));
+                        }
+                        const double mu = (double)climb_eps + (double)tri_margin[i];
+                        unsigned x = leafx[i];
+                        int level = 0;
+                        for (;;) {
+                            const float* b = &rec[(size_t)(x >> 1) * 16 + 6 * (x & 1u)];
+                            bool inside = true;
+                            for (int c = 0; c < 3; ++c) inside = inside && (lo[c] - (double)b[c] >= mu) && ((double)b[3 + c] - hi[c] >= mu);
+                            if (inside) break;
+                            ++level;
+                            const int up = parentx[x >> 1];
+                            if (up < 0) break;
+                            x = (unsigned)up;
+                        }
+                        leafx[i] |= (unsigned)(level < 255 ? level : 255) << 24;
                     }
                 }
             }
@@ -1451,7 +1496,8 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
     s->dev.cull_eps = cull_eps;
     s->dev.nodes2 = (const float4*)s->d_nodes2;
     s->dev.ttri2 = (const float4*)s->d_ttri2;
-    s->dev.map2 = (const int*)s->d_map2, s->dev.leafx = (const int*)s->d_leafx, s->dev.parentx = (const int*)s->d_parentx;
+    s->dev.map2 = (const int*)s->d_map2, s->dev.leafx = (const unsigned*)s->d_leafx, s->dev.parentx = (const int*)s->d_parentx;
+    s->dev.climb_eps = climb_eps;
     s->dev.root_entry2 = root_entry2;
     s->dev.has_entry = has_entry ? 1 : 0;
     *out = s;

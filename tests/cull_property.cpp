@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
         } while (n < 1e-6);
         v[0] /= n, v[1] /= n, v[2] /= n;
     };
-    long long accepted = 0, checked = 0, violations = 0, ineligible = 0;
+    long long accepted = 0, checked = 0, violations = 0, ineligible = 0, interior_checked = 0;
     double worst = 0.0;
     long long by_kind[4] = {0, 0, 0, 0};
     for (long long it = 0; it < samples; ++it) {
@@ -108,6 +108,22 @@ int main(int argc, char** argv) {
             ++ineligible;  // never culled
             continue;
         }
+        // ---- short climb: a box that contains the triangle with a margin of mu = 4 * scene margin + shape
+        // margin on all six sides passes the REFERENCE's own box test for this ray, for certain (rays with eps_ray <= 4 * scene) ----
+        if (eps_ray <= 4.0f * scene_eps) {
+            const float mu = 4.0f * scene_eps + eps_box;
+            vec3 A = min3(p1, min3(p2, p3)), B = max3(p1, max3(p2, p3));
+            for (int rep = 0; rep < 3; ++rep) {
+                const float g = mu * (1.0f + (float)(rep * rep) * (float)U(gen) * 50.0f);
+                // grow by at least mu: round the grown faces outwards
+                const vec3 A2 = v3(nextafterf(A.x - g, -INFINITY), nextafterf(A.y - g, -INFINITY), nextafterf(A.z - g, -INFINITY));
+                const vec3 B2 = v3(nextafterf(B.x + g, INFINITY), nextafterf(B.y + g, INFINITY), nextafterf(B.z + g, INFINITY));
+                ++interior_checked;
+                if (!(hitAABB(S, invdir, A2, B2) > 0.0f)) {
+                    if (++violations <= 10) fprintf(stderr, "VIOLATION kind %d: interior box refused by the reference's hitAABB, t %.9g mu %g\n", kind, t, mu);
+                }
+            }
+        }
         // ---- boxes that contain the triangle: the tight one and randomly grown ones (ancestors) ----
         vec3 AA = min3(p1, min3(p2, p3)), BB = max3(p1, max3(p2, p3));
         for (int rep = 0; rep < 4; ++rep) {
@@ -132,8 +148,8 @@ int main(int argc, char** argv) {
             BB = BB + v3((float)U(gen) * grow, (float)U(gen) * grow, (float)U(gen) * grow);
         }
     }
-    printf("cull_property: %lld samples, %lld accepted hits (ordinary %lld, needle %lld, sliver %lld, strip %lld), %lld never-cull, %lld box checks, "
+    printf("cull_property: %lld samples, %lld accepted hits (ordinary %lld, needle %lld, sliver %lld, strip %lld), %lld never-cull, %lld box checks, %lld interior-box checks, "
            "%lld violations, largest margin fraction needed %.4f (safety factor %.1f)\n",
-           samples, accepted, by_kind[0], by_kind[1], by_kind[2], by_kind[3], ineligible, checked, violations, worst, worst > 0 ? 1.0 / worst : 0.0);
+           samples, accepted, by_kind[0], by_kind[1], by_kind[2], by_kind[3], ineligible, checked, interior_checked, violations, worst, worst > 0 ? 1.0 / worst : 0.0);
     return violations ? 1 : 0;
 }
