@@ -58,6 +58,13 @@ __device__ __align__(16) const unsigned d_sobolV[8 * 32] = {
 // profiling builds only (-DRT_OP_CYCLES): s_memtime ticks spent in each kind of pass, summed over waves
 __device__ unsigned long long g_opcycles[8];
 #endif
+#ifdef RT_SHADE_CYCLES
+// profiling builds only (-DRT_SHADE_CYCLES): s_memtime ticks per step of the shade pass, summed over waves; [15] = passes
+__device__ unsigned long long g_shadecycles[16];
+#define SHADE_MARK(k_) do { const long long t_ = clock64(); scy[k_] += (unsigned long long)(t_ - scy_t); scy_t = t_; } while (0)
+#else
+#define SHADE_MARK(k_) do { } while (0)
+#endif
 
 // ---- device view of a scene ------------------------------------------------------------------------------------
 struct DevScene {
@@ -397,6 +404,10 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     unsigned long long paths = 0;
     unsigned dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // STATS builds: passes / active-lane sums per op
     unsigned sg[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // STATS builds: lanes taking each step of the shade pass
+#ifdef RT_SHADE_CYCLES
+    unsigned long long scy[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long scy_t = 0;
+#endif
 
     // lane state
     int op = OP_DONE;
@@ -468,6 +479,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             vec3 f_r = v3(0);
             float pdf_brdf = 0.0f;
             const bool need_eval = isD || (h && kind == K_SHADOW && miss);
+#ifdef RT_SHADE_CYCLES
+            scy_t = clock64(), scy[8]++;
+#endif
             if (STATS) { const int c_ = __popcll(__ballot(need_eval)); if (lane == 0) sg[0] += c_; }
             if (need_eval) {
                 if (MODE == RT_MODE_CHAP5) {
@@ -489,6 +503,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             const bool need_env = (isA && miss) || (h && kind == K_SHADOW && miss) || (d_alive && miss);
             vec3 color = v3(0);
             float pdf_light = 0.0f;
+            SHADE_MARK(0);  // BRDF eval
             if (STATS) { const int c_ = __popcll(__ballot(need_env)); if (lane == 0) sg[1] += c_; }
             if (need_env) {
                 if (sc.hdr) {
@@ -502,6 +517,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     if (MODE == RT_MODE_CHAP5 && !isA) pdf_light = hdrPdfConvert(c.w, ew, sc.hdrW);
                 }
             }
+            SHADE_MARK(1);  // env lookup
             // step 3: what each kind of ray adds
             if (isA && miss) {
                 Lo = color, first_tri = -1, fin = true;
@@ -533,6 +549,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 fin = true;
             }
             // step 4: the ray hit a surface: finish the hit record (smooth normal), move the path there
+            SHADE_MARK(2);  // contributions
             if (STATS) { const int c_ = __popcll(__ballot((isA || d_alive) && !miss)); if (lane == 0) sg[2] += c_; }
             if ((isA || d_alive) && !miss) {
                 const Hit nh = finish_hit<MODE>(sc, S, L, best_tri, best);
@@ -555,6 +572,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 if (bounce < P.max_bounce) to_B = true; else fin = true;
             }
             // ---- start of a bounce (f5:856-866 env sample; chapters 3/4: the hemisphere sample) ------------------
+            SHADE_MARK(3);  // finish hit
             if (STATS) { const int c_ = __popcll(__ballot(to_B)); if (lane == 0) sg[3] += c_; }
             if (to_B) {
                 if (MODE == RT_MODE_CHAP5) {
@@ -574,6 +592,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 }
             }
             // ---- BRDF importance sampling (f5:883-895): after the env-visibility ray, or at once when it was skipped ---
+            SHADE_MARK(4);  // bounce start
             if (STATS) { const int c_ = __popcll(__ballot(isC || to_C)); if (lane == 0) sg[4] += c_; }
             if (MODE == RT_MODE_CHAP5 && (isC || to_C)) {
                 const MatPre pre = load_mat_pre(sc, surf_tri);
@@ -589,6 +608,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 }
             }
             // ---- end of a sample: Le + Li (f5:950) goes to the launch's sample buffer ----------------------------------
+            SHADE_MARK(5);  // BRDF sampling
             if (STATS) { const int c_ = __popcll(__ballot(fin)); if (lane == 0) sg[5] += c_; }
             if (fin) {
                 vec3 sample = Lo;
@@ -666,6 +686,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 }
             }
             // ---- hitBVH prologue (f5:260-268) --------------------------------------------------------------------
+            SHADE_MARK(6);  // end of sample + next sample + camera ray
             if (STATS) { const int c_ = __popcll(__ballot(emit)); if (lane == 0) sg[6] += c_; }
             if (emit) {
                 if (STATS) st.rays++;
@@ -687,6 +708,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     if (STATS) st.leaves++;
                 }
             }
+            SHADE_MARK(7);  // ray prologue
         } else if (pick == OP_INT) {
             // ---- one internal node (f5:282-307) ------------------------------------------------------------------
             if (op == OP_INT) {
@@ -903,6 +925,10 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
         for (int k = 0; k < 4; ++k) atomicAdd(&g_opcycles[k], oc[k]);
         atomicAdd(&g_opcycles[4], 1ull);
     }
+#endif
+#ifdef RT_SHADE_CYCLES
+    if (lane == 0)
+        for (int k = 0; k < 9; ++k) atomicAdd(&g_shadecycles[k], scy[k]);
 #endif
     if (STATS) {
         flush_stats(P, st, paths);
@@ -2043,6 +2069,20 @@ int rt_kernel_time_ms(float* avg_ms, int* launches, int reset) {
     }
     if (avg_ms) *avg_ms = n ? (float)(total / n) : 0.0f;
     if (launches) *launches = n;
+#ifdef RT_SHADE_CYCLES
+    {
+        unsigned long long h[16] = {0}, z[16] = {0};
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shadecycles), sizeof(h)) == hipSuccess && h[8]) {
+            static const char* nm[8] = {"BRDF eval", "env lookup", "contributions", "finish hit", "bounce start", "BRDF sampling", "end + next sample", "ray prologue"};
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) tot += (double)h[k];
+            for (int k = 0; k < 8; ++k)
+                fprintf(stderr, "[rt shade] %-18s %6.1f ticks per pass  %5.1f%%\n", nm[k], (double)h[k] / (double)h[8], 100.0 * h[k] / tot);
+            fprintf(stderr, "[rt shade] %llu passes, %.0f ticks per pass\n", h[8], tot / (double)h[8]);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shadecycles), z, sizeof(z));
+        }
+    }
+#endif
 #ifdef RT_OP_CYCLES
     {
         unsigned long long h[8] = {0}, z[8] = {0};
