@@ -57,6 +57,31 @@ def test_noalloc_sum_mode_and_deep_tree_spill_from_scratch(hdr_pair):
     assert np.array_equal(_bits(a), _bits(b))
 
 
+def test_noalloc_with_the_entry_bvh_and_interleaved_with_overlapped_calls(scene_small, hdr_pair):
+    """A scene that walks the entry BVH (forced), rendered alternately through the allocating entry point (one-frame calls,
+    overlapped on the internal streams) and the no-allocation one on the same caller stream: both accumulate the same frames."""
+    import torch
+    dev = torch.device("cuda", 0)
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache, device=0, entry_bvh=1)
+    assert sc.info().entry_bvh == 1
+    eye, cam = rt.camera(-30.0, 25.0, 3.0)
+    d = rt.make_desc(120, 90, mode=5, eye=eye, camera_rotate=cam)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    a = torch.zeros((90, 120, 3), dtype=torch.float32, device=dev)
+    b = torch.zeros_like(a)
+    for f in range(9):
+        sc.render_device(d, f, 1, a.data_ptr(), stream)
+        sc.render_device_noalloc(d, f, 1, b.data_ptr(), stream)
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(_bits(a), _bits(b))
+    c = torch.zeros_like(a)
+    sc.render_device_noalloc(d, 0, 9, c.data_ptr(), stream)
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(_bits(a), _bits(c))
+
+
 def test_noalloc_rejects_what_does_not_fit(scene_small, hdr_pair):
     import torch
     tris, nodes = scene_small
