@@ -8,12 +8,27 @@
 //
 // Sibling subtrees work on disjoint ranges, so they are built as OpenMP tasks into a pointer tree, which is then numbered
 // in the reference's order (a node before its left subtree, the whole left subtree before the right one).  Inside a node the
-// four sorts stay sequential: each starts from the order the previous one left, as in the reference.
+// four sorts stay in sequence: each starts from the order the previous one left, as in the reference.
+//
+// The nodes near the root are where a 10 M-triangle build spends its time if each is one thread's work (the root alone: four
+// sorts of the whole array and three sweeps).  Ranges of at least kParNodeMin triangles are therefore processed by all
+// threads — with results that are still the sequential ones, bit for bit:
+//   * the sorts through exact_sort.h (libstdc++'s own introsort steps, run as tasks on disjoint ranges: the permutation
+//     std::sort produces, ties included);
+//   * the bounding box and the prefix / suffix boxes in chunks: GLM's min(a, b) keeps `a` unless b < a, so a running
+//     minimum is the FIRST occurrence of the smallest value (this only matters for the sign of a zero); a chunk's own
+//     fold has the same property, and folding the chunk results in order again keeps the first — the chunked value IS the
+//     sequential one, and each chunk then continues the sequential recurrence from it;
+//   * the cost sweep per chunk with the strict `<` of c5:566, chunk results combined in order with the same strict `<`.
+// Needs finite coordinates (a strict weak order for the sorts, no NaN in the folds); otherwise the sequential path runs.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 
+#include "exact_sort.h"
 #include "rt_host.h"
 
 namespace rta {
@@ -42,12 +57,24 @@ struct TNode {  // node of the tree as it is built; numbered afterwards
     TNode *left, *right;
 };
 constexpr int kTaskMin = 8192;  // ranges at least this long build their two subtrees as parallel tasks
+constexpr int kParNodeMin = 1 << 17;  // ranges at least this long are sorted and swept by all threads
+constexpr int kChunk = 1 << 15;       // chunk of such a range handled by one task
+
+template <class F>
+void par_chunks(int n_chunks, F&& f) {
+#pragma omp taskgroup
+    for (int c = 0; c < n_chunks; ++c) {
+#pragma omp task default(shared) firstprivate(c)
+        f(c);
+    }
+}
 
 struct Builder {
     std::vector<Proxy> px;
     std::vector<vec3> tmin, tmax;  // per original triangle: min/max over p1,p2,p3 as min(p1, min(p2, p3))
     std::vector<BNode> nodes;
     int leaf_n;
+    bool par_ok = false;  // every coordinate finite: large ranges may take the chunked path
 
     TNode* new_node(int l, int r) {
         TNode* nd = new TNode();
@@ -55,6 +82,18 @@ struct Builder {
         nd->n = nd->index = 0;
         nd->AA = v3(1145141919, 1145141919, 1145141919);
         nd->BB = v3(-1145141919, -1145141919, -1145141919);
+        if (par_ok && r - l + 1 >= kParNodeMin) {
+            const int cnt = r - l + 1, nch = (cnt + kChunk - 1) / kChunk;
+            std::vector<vec3> cmin(nch), cmax(nch);
+            par_chunks(nch, [&](int c) {
+                const int b = l + c * kChunk, e = std::min(b + kChunk, r + 1);
+                vec3 mn = tmin[px[b].idx], mx = tmax[px[b].idx];
+                for (int i = b + 1; i < e; ++i) mn = min3(mn, tmin[px[i].idx]), mx = max3(mx, tmax[px[i].idx]);
+                cmin[c] = mn, cmax[c] = mx;
+            });
+            for (int c = 0; c < nch; ++c) nd->AA = min3(nd->AA, cmin[c]), nd->BB = max3(nd->BB, cmax[c]);
+            return nd;
+        }
         for (int i = l; i <= r; i++) {
             const vec3 mn = tmin[px[i].idx], mx = tmax[px[i].idx];
             nd->AA.x = fmin_(nd->AA.x, mn.x), nd->AA.y = fmin_(nd->AA.y, mn.y), nd->AA.z = fmin_(nd->AA.z, mn.z);
@@ -80,9 +119,76 @@ struct Builder {
     void sort_axis(int axis, int l, int r) {
         Proxy* b = px.data() + l;
         Proxy* e = px.data() + r + 1;
+        if (par_ok && r - l + 1 >= kParNodeMin) {  // std::sort's permutation, computed by all threads
+            if (axis == 0) exact_sort(b, e, cmpx);
+            if (axis == 1) exact_sort(b, e, cmpy);
+            if (axis == 2) exact_sort(b, e, cmpz);
+            return;
+        }
         if (axis == 0) std::sort(b, e, cmpx);
         if (axis == 1) std::sort(b, e, cmpy);
         if (axis == 2) std::sort(b, e, cmpz);
+    }
+
+    // One axis of the SAH sweep (c5:509-575) over a large range, in chunks; same values as the sequential loops of build_sah.
+    void sweep_chunked(int l, int r, vec3* leftMax, vec3* leftMin, vec3* rightMax, vec3* rightMin, float* cost_out, float* split_out) {
+        const int cnt = r - l + 1, nch = (cnt + kChunk - 1) / kChunk;
+        std::vector<vec3> fmn(nch), fmx(nch), bmn(nch), bmx(nch);  // per chunk: forward and backward folds
+        par_chunks(nch, [&](int c) {
+            const int b = l + c * kChunk, e = std::min(b + kChunk, r + 1);
+            vec3 mn = tmin[px[b].idx], mx = tmax[px[b].idx];
+            for (int i = b + 1; i < e; ++i) mn = min3(mn, tmin[px[i].idx]), mx = max3(mx, tmax[px[i].idx]);
+            fmn[c] = mn, fmx[c] = mx;
+            mn = tmin[px[e - 1].idx], mx = tmax[px[e - 1].idx];
+            for (int i = e - 2; i >= b; --i) mn = min3(mn, tmin[px[i].idx]), mx = max3(mx, tmax[px[i].idx]);
+            bmn[c] = mn, bmx[c] = mx;
+        });
+        std::vector<vec3> pmn(nch), pmx(nch), smn(nch), smx(nch);  // the running values just before / after each chunk
+        vec3 amn = v3(kINF), amx = v3(-kINF);
+        for (int c = 0; c < nch; ++c) pmn[c] = amn, pmx[c] = amx, amn = min3(amn, fmn[c]), amx = max3(amx, fmx[c]);
+        amn = v3(kINF), amx = v3(-kINF);
+        for (int c = nch - 1; c >= 0; --c) smn[c] = amn, smx[c] = amx, amn = min3(amn, bmn[c]), amx = max3(amx, bmx[c]);
+        par_chunks(nch, [&](int c) {
+            const int b = l + c * kChunk, e = std::min(b + kChunk, r + 1);
+            vec3 mn = pmn[c], mx = pmx[c];
+            for (int i = b; i < e; ++i) {
+                mx = max3(mx, tmax[px[i].idx]), mn = min3(mn, tmin[px[i].idx]);
+                leftMax[i - l] = mx, leftMin[i - l] = mn;
+            }
+            mn = smn[c], mx = smx[c];
+            for (int i = e - 1; i >= b; --i) {
+                mx = max3(mx, tmax[px[i].idx]), mn = min3(mn, tmin[px[i].idx]);
+                rightMax[i - l] = mx, rightMin[i - l] = mn;
+            }
+        });
+        std::vector<float> ccost(nch), csplit(nch);
+        par_chunks(nch, [&](int c) {
+            const int b = l + c * kChunk, e = std::min(b + kChunk, r);  // i <= r - 1
+            float cost = kINF;
+            float split = l;
+            for (int i = b; i < e; ++i) {
+                float lenx, leny, lenz;
+                const vec3 leftAA = leftMin[i - l], leftBB = leftMax[i - l];
+                lenx = leftBB.x - leftAA.x, leny = leftBB.y - leftAA.y, lenz = leftBB.z - leftAA.z;
+                const float leftS = 2.0 * ((lenx * leny) + (lenx * lenz) + (leny * lenz));
+                const float leftcost = leftS * (i - l + 1);
+                const vec3 rightAA = rightMin[i - l + 1], rightBB = rightMax[i - l + 1];
+                lenx = rightBB.x - rightAA.x, leny = rightBB.y - rightAA.y, lenz = rightBB.z - rightAA.z;
+                const float rightS = 2.0 * ((lenx * leny) + (lenx * lenz) + (leny * lenz));
+                const float rightcost = rightS * (r - i);
+                const float totalCost = rightcost + leftcost;
+                if (totalCost < cost) {
+                    cost = totalCost;
+                    split = i;
+                }
+            }
+            ccost[c] = cost, csplit[c] = split;
+        });
+        float cost = kINF;
+        float split = l;
+        for (int c = 0; c < nch; ++c)
+            if (ccost[c] < cost) cost = ccost[c], split = csplit[c];
+        *cost_out = cost, *split_out = split;
     }
 
     TNode* build_sah(int l, int r) {
@@ -97,24 +203,48 @@ struct Builder {
         int Axis = 0;
         int Split = (l + r) / 2;
         const int cnt = r - l + 1;
-        std::vector<vec3> leftMax(cnt), leftMin(cnt), rightMax(cnt), rightMin(cnt);
+        if (par_ok && cnt >= kParNodeMin) {
+            {
+                std::unique_ptr<vec3[]> lMax(new vec3[cnt]), lMin(new vec3[cnt]), rMax(new vec3[cnt]), rMin(new vec3[cnt]);
+                for (int axis = 0; axis < 3; axis++) {
+                    sort_axis(axis, l, r);
+                    float cost, split;
+                    sweep_chunked(l, r, lMax.get(), lMin.get(), rMax.get(), rMin.get(), &cost, &split);
+                    if (cost < Cost) {
+                        Cost = cost;
+                        Axis = axis;
+                        Split = split;
+                    }
+                }
+            }
+            sort_axis(Axis, l, r);
+#pragma omp task default(shared)
+            nd->left = build_sah(l, Split);
+#pragma omp task default(shared)
+            nd->right = build_sah(Split + 1, r);
+#pragma omp taskwait
+            return nd;
+        }
+        // prefix / suffix boxes of the sweep (c5:509-541) in this thread's scratch: no task scheduling point until they are
+        // dead, so the buffer cannot be taken over by another node in between.  The reference fills them with -INF / INF and
+        // folds in place; the running values below are the same recurrence with those initial values.
+        static thread_local std::vector<vec3> scratch;
+        if (scratch.size() < 4 * (size_t)cnt) scratch.resize(4 * (size_t)cnt);
+        vec3* const leftMax = scratch.data();
+        vec3* const leftMin = leftMax + cnt;
+        vec3* const rightMax = leftMin + cnt;
+        vec3* const rightMin = rightMax + cnt;
         for (int axis = 0; axis < 3; axis++) {
             sort_axis(axis, l, r);
-            std::fill(leftMax.begin(), leftMax.end(), v3(-kINF));
-            std::fill(leftMin.begin(), leftMin.end(), v3(kINF));
+            vec3 amx = v3(-kINF), amn = v3(kINF);
             for (int i = l; i <= r; i++) {
-                const vec3 mn = tmin[px[i].idx], mx = tmax[px[i].idx];
-                const int bias = (i == l) ? 0 : 1;
-                leftMax[i - l] = max3(leftMax[i - l - bias], mx);
-                leftMin[i - l] = min3(leftMin[i - l - bias], mn);
+                amx = max3(amx, tmax[px[i].idx]), amn = min3(amn, tmin[px[i].idx]);
+                leftMax[i - l] = amx, leftMin[i - l] = amn;
             }
-            std::fill(rightMax.begin(), rightMax.end(), v3(-kINF));
-            std::fill(rightMin.begin(), rightMin.end(), v3(kINF));
+            amx = v3(-kINF), amn = v3(kINF);
             for (int i = r; i >= l; i--) {
-                const vec3 mn = tmin[px[i].idx], mx = tmax[px[i].idx];
-                const int bias = (i == r) ? 0 : 1;
-                rightMax[i - l] = max3(rightMax[i - l + bias], mx);
-                rightMin[i - l] = min3(rightMin[i - l + bias], mn);
+                amx = max3(amx, tmax[px[i].idx]), amn = min3(amn, tmin[px[i].idx]);
+                rightMax[i - l] = amx, rightMin[i - l] = amn;
             }
             float cost = kINF;
             float split = l;  // `float split`, c5:545
@@ -141,8 +271,6 @@ struct Builder {
             }
         }
         sort_axis(Axis, l, r);
-        { std::vector<vec3>().swap(leftMax); std::vector<vec3>().swap(leftMin); }
-        { std::vector<vec3>().swap(rightMax); std::vector<vec3>().swap(rightMin); }
         if (cnt >= kTaskMin) {
 #pragma omp task default(shared)
             nd->left = build_sah(l, Split);
@@ -200,15 +328,19 @@ extern "C" int rt_bvh_build(rt_mesh* mesh, int leaf_n, int use_sah, float** node
     b.px.resize(nT);
     b.tmin.resize(nT);
     b.tmax.resize(nT);
+    bool all_finite = true;
+#pragma omp parallel for schedule(static) reduction(&& : all_finite)
     for (int i = 0; i < nT; ++i) {
         const TriRec& t = mesh->tris[i];
         const vec3 c = (t.p1 + t.p2 + t.p3) / v3(3, 3, 3);
+        all_finite = all_finite && fabsf(c.x) < INFINITY && fabsf(c.y) < INFINITY && fabsf(c.z) < INFINITY;  // (then p1, p2, p3 are finite too)
         b.px[i].cx = c.x, b.px[i].cy = c.y, b.px[i].cz = c.z, b.px[i].idx = i;
         b.tmin[i] = v3(fmin_(t.p1.x, fmin_(t.p2.x, t.p3.x)), fmin_(t.p1.y, fmin_(t.p2.y, t.p3.y)),
                        fmin_(t.p1.z, fmin_(t.p2.z, t.p3.z)));
         b.tmax[i] = v3(fmax_(t.p1.x, fmax_(t.p2.x, t.p3.x)), fmax_(t.p1.y, fmax_(t.p2.y, t.p3.y)),
                        fmax_(t.p1.z, fmax_(t.p2.z, t.p3.z)));
     }
+    b.par_ok = all_finite;
     // dummy node 0 (c5:835-841); its fields are never read by a valid traversal.
     b.nodes.push_back(BNode());
     memset((void*)&b.nodes[0], 0, sizeof(BNode));
@@ -219,6 +351,7 @@ extern "C" int rt_bvh_build(rt_mesh* mesh, int leaf_n, int use_sah, float** node
     b.number(root);
 
     std::vector<TriRec> permuted((size_t)nT);
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < nT; ++i) permuted[i] = mesh->tris[b.px[i].idx];
     mesh->tris.swap(permuted);
 

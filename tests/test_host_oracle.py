@@ -171,6 +171,54 @@ def test_bvh_builders_equal_oracle_on_tie_heavy_input(sah, leaf_n):
     assert np.array_equal(bits(pn[1:]), bits(on[1:]))
 
 
+def _write_lattice_obj(path, layers, nx, nz):
+    """`layers` stacked nx x nz grids of unit cells, two triangles per cell: centroid coordinates tie by the thousand on every axis."""
+    with open(path, "w") as f:
+        for k in range(layers):
+            for i in range(nx + 1):
+                for j in range(nz + 1):
+                    f.write(f"v {i} {k} {j}\n")
+        for k in range(layers):
+            base = k * (nx + 1) * (nz + 1) + 1
+            for i in range(nx):
+                for j in range(nz):
+                    a = base + i * (nz + 1) + j
+                    b, c, d = a + (nz + 1), a + (nz + 1) + 1, a + 1
+                    f.write(f"f {a} {b} {c}\nf {a} {c} {d}\n")
+
+
+@pytest.mark.parametrize("sah", [True, False])
+def test_large_node_path_of_the_bvh_builders_equals_oracle(tmp_path, sah):
+    """Ranges of >= 131 072 triangles are sorted and swept by all threads (csrc/exact_sort.h, chunked sweeps in host_bvh.cpp);
+    the result must still be the sequential build's — the oracle sorts with std::sort and sweeps in one loop — on an input
+    where almost every comparison ties."""
+    obj = str(tmp_path / "lattice.obj")
+    _write_lattice_obj(obj, 6, 180, 140)  # 302 400 triangles
+    pm, om = rt.Mesh(), O.Mesh()
+    mat = rt.Material(baseColor=(0.5, 0.5, 0.5))
+    tr = ((0, 0, 0), (0.1, -0.2, 0.3), (2.0, 1.5, 2.5))
+    pm.readObj(obj, mat, rt.getTransformMatrix(*tr), False)
+    om.read_obj(obj, mat.as_array(), O.transform_matrix(*tr), False)
+    assert len(pm) == 302400
+    pn = pm.buildBVHwithSAH(8) if sah else pm.buildBVH(8)
+    on = om.build(8, sah)
+    assert np.array_equal(bits(pm.triangles()), bits(om.triangles()))
+    assert np.array_equal(bits(pn[1:]), bits(on[1:]))
+
+
+def test_exact_sort_equals_std_sort(tmp_path):
+    """tests/exact_sort_test.cpp: the parallel driver of libstdc++'s introsort steps leaves every array exactly as std::sort
+    does (tie-heavy, sorted, reversed, organ-pipe, all-equal inputs, signed zeros, exhausted depth limits, the builder's
+    x / y / x / y sequence)."""
+    import subprocess
+    exe = str(tmp_path / "exact_sort_test")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", os.path.join(ROOT, "tests", "exact_sort_test.cpp"), "-o", exe],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="8"))
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
 def test_empty_and_tiny_meshes():
     m = rt.Mesh()
     nodes = m.buildBVHwithSAH(8)
