@@ -99,8 +99,8 @@ void rt_free(void* p);
 
 /* On-disk scene cache (no counterpart in the reference, which rebuilds its BVH at every start, c5:843).
  * The file holds the two arrays the reference uploads — Triangle_encoded[] (c5:54-64) in its final permuted order and
- * BVHNode_encoded[] (c5:65-70) — raw little-endian fp32 behind a 48-byte header (magic "RTAMDSC1", record sizes, `key`,
- * counts, FNV-1a-64 of the payload).  `key` is the caller's hash of whatever the arrays were built from (OBJ bytes,
+ * BVHNode_encoded[] (c5:65-70) — raw little-endian fp32 behind a 48-byte header (magic "RTAMDSC2", record sizes, `key`,
+ * counts, and a payload hash: FNV-1a-64 over the FNV-1a-64 hashes of the payload's 4 MiB blocks, hashed by all cores).  `key` is the caller's hash of whatever the arrays were built from (OBJ bytes,
  * materials, transforms, leaf size): rt_scene_cache_load refuses a file whose key differs (RT_ERR_FORMAT), is truncated
  * or whose payload hash is wrong.  Loaded arrays are released with rt_free.  rt_hash_fnv1a64(seed = 0) starts a hash;
  * pass the previous result as `seed` to chain buffers. */

@@ -7,26 +7,46 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <vector>
+
 #include "rt_host.h"
 
 namespace {
 
 struct CacheHeader {
-    char magic[8];        // "RTAMDSC1"
+    char magic[8];        // "RTAMDSC2"
     uint32_t tri_floats;  // 36
     uint32_t node_floats; // 12
     uint64_t key;
     uint64_t n_triangles;
     uint64_t n_nodes;
-    uint64_t payload_hash;  // FNV-1a 64 over the two arrays as stored
+    uint64_t payload_hash;  // payload_hash() of the two arrays as stored
 };
 static_assert(sizeof(CacheHeader) == 48, "header layout is part of the file format");
-const char kMagic[8] = {'R', 'T', 'A', 'M', 'D', 'S', 'C', '1'};
+const char kMagic[8] = {'R', 'T', 'A', 'M', 'D', 'S', 'C', '2'};
 
 uint64_t fnv1a64(const void* data, size_t n, uint64_t h) {
     const unsigned char* p = (const unsigned char*)data;
     for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
     return h;
+}
+
+// The payload hash: FNV-1a 64 over the FNV-1a 64 hashes of the payload's 4 MiB blocks (triangles, then nodes; the last block
+// of each array may be short).  A byte-serial hash over a 1.6 GB file is 1.6 s of one core at every start; the blocks are
+// hashed by all cores (format version 2 — version-1 files are rejected as "not a scene cache file" and rebuilt).
+constexpr size_t kHashBlock = 4u << 20;
+uint64_t block_hashes(const void* data, size_t n, uint64_t h) {
+    const size_t nb = (n + kHashBlock - 1) / kHashBlock;
+    std::vector<uint64_t> bh(nb);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t b = 0; b < nb; ++b) {
+        const size_t off = b * kHashBlock, len = (n - off < kHashBlock) ? n - off : kHashBlock;
+        bh[b] = fnv1a64((const unsigned char*)data + off, len, 0xcbf29ce484222325ull);
+    }
+    return fnv1a64(bh.data(), nb * sizeof(uint64_t), h);
+}
+uint64_t payload_hash(const void* tris, size_t tb, const void* nodes, size_t nb) {
+    return block_hashes(nodes, nb, block_hashes(tris, tb, 0xcbf29ce484222325ull));
 }
 
 }  // namespace
@@ -47,7 +67,7 @@ int rt_scene_cache_save(const char* path, uint64_t key, const float* tris, int n
     h.tri_floats = 36, h.node_floats = 12, h.key = key;
     h.n_triangles = (uint64_t)n_triangles, h.n_nodes = (uint64_t)n_nodes;
     const size_t tb = (size_t)n_triangles * 36 * sizeof(float), nb = (size_t)n_nodes * 12 * sizeof(float);
-    h.payload_hash = fnv1a64(nodes, nb, fnv1a64(tris, tb, 0xcbf29ce484222325ull));
+    h.payload_hash = payload_hash(tris, tb, nodes, nb);
     // write a uniquely named file beside the target and rename it, so a reader never sees a half-written file and ranks
     // that hit a cold cache together (one process per GPU) do not write through each other
     char tmp[4096];
@@ -92,7 +112,7 @@ int rt_scene_cache_load(const char* path, uint64_t key, float** tris_out, int* n
             rc = set_error(RT_ERR_OOM, "rt_scene_cache_load: out of memory");
         } else if ((tb && fread(t, 1, tb, f) != tb) || (nb && fread(n, 1, nb, f) != nb) || fgetc(f) != EOF) {
             rc = set_error(RT_ERR_FORMAT, "rt_scene_cache_load: %s is truncated or has trailing bytes", path);
-        } else if (fnv1a64(n, nb, fnv1a64(t, tb, 0xcbf29ce484222325ull)) != h.payload_hash) {
+        } else if (payload_hash(t, tb, n, nb) != h.payload_hash) {
             rc = set_error(RT_ERR_FORMAT, "rt_scene_cache_load: %s is corrupt (payload hash mismatch)", path);
         }
     }

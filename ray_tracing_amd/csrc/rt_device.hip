@@ -41,7 +41,6 @@ constexpr int kBlock = 256;      // primary_kernel: 16x16 pixels; each wave64 ow
 #define RT_WAVES_PER_EU 5
 #endif
 constexpr int kLdsDepth = RT_LDS_DEPTH;    // per-lane stack entries kept in LDS
-constexpr int kMaxStack = 256;   // int stack[256], f5:265
 
 // Sobol direction numbers, f5:339 (data table: 8 dimensions x 32 bits)
 __device__ __align__(16) const unsigned d_sobolV[8 * 32] = {
@@ -91,7 +90,6 @@ struct DevScene {
 };
 
 // packed stack entry: >= 0 internal record index; < 0 leaf: bit31 | (n-1) << 24 | first triangle index
-__host__ __device__ inline int pack_leaf(int index, int n) { return (int)(0x80000000u | ((unsigned)(n - 1) << 24) | (unsigned)index); }
 
 struct Stats {
     unsigned rays, internal, leaves, tris, updates;
@@ -287,7 +285,6 @@ __device__ __forceinline__ Mat load_material(const DevScene& sc, int tri) {
     return m;
 }
 
-constexpr int kDmatVec = 6;  // float4s per triangle in `dmat`: MatPre (4) + the material fields chapter 5's BRDF reads per evaluation (2)
 __device__ __forceinline__ MatPre load_mat_pre(const DevScene& sc, int tri) {
     const float4 a = sc.dmat[tri * kDmatVec + 0], b = sc.dmat[tri * kDmatVec + 1], c = sc.dmat[tri * kDmatVec + 2], d = sc.dmat[tri * kDmatVec + 3];
     MatPre q;
@@ -1080,14 +1077,6 @@ struct rt_scene {
     float cost_ref = 0.0f, cost_entry = 0.0f;  // expected internal-node visits of a random line: reference tree, entry BVH
 };
 
-static int f2i_checked(float f, int* out) {
-    if (!(f >= -1.0f && f < 16777216.0f)) return 0;
-    const int i = (int)f;
-    if ((float)i != f) return 0;
-    *out = i;
-    return 1;
-}
-
 extern "C" {
 
 int rt_init(int device) {
@@ -1140,296 +1129,20 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
         if (rc != RT_OK) return rc;
     }
 
-    // ---- validate the BVH (root = node 1, f5:268) and number the internal nodes in pre-order -----------------
-    const NodeRec* N = (const NodeRec*)nodes;
-    std::vector<int> rec_of(nN > 0 ? nN : 0, -1);   // internal node -> record index
-    std::vector<int> entry(nN > 0 ? nN : 0, 0);     // node -> packed entry
-    std::vector<int> order;                        // internal nodes in record order
-    int max_depth = 0;
-    const bool has_root = nN >= 2;
-    if (has_root) {
-        std::vector<char> seen(nN, 0);
-        std::vector<std::pair<int, int>> stack;  // node, depth
-        stack.push_back({1, 0});
-        while (!stack.empty()) {
-            const int id = stack.back().first, depth = stack.back().second;
-            stack.pop_back();
-            if (id < 1 || id >= nN) return set_error(RT_ERR_BAD_BVH, "rt_scene_create: node index %d out of range [1,%d)", id, nN);
-            if (seen[id]) return set_error(RT_ERR_BAD_BVH, "rt_scene_create: node %d reachable twice (not a tree)", id);
-            seen[id] = 1;
-            if (depth > max_depth) max_depth = depth;
-            int l, r, n, index;
-            if (!f2i_checked(N[id].left, &l) || !f2i_checked(N[id].right, &r) || !f2i_checked(N[id].n, &n) ||
-                !f2i_checked(N[id].index, &index))
-                return set_error(RT_ERR_BAD_BVH, "rt_scene_create: node %d holds a non-integral index field", id);
-            if (n > 0) {  // leaf, f5:274
-                if (n > 128) return set_error(RT_ERR_BAD_BVH, "rt_scene_create: leaf %d holds %d triangles (max 128)", id, n);
-                if (index < 0 || (long long)index + n > nT)
-                    return set_error(RT_ERR_BAD_BVH, "rt_scene_create: leaf %d range [%d,%d) outside the %d triangles", id, index, index + n, nT);
-                entry[id] = pack_leaf(index, n);
-            } else {
-                if (l <= 0 || r <= 0)
-                    return set_error(RT_ERR_BAD_BVH, "rt_scene_create: internal node %d lacks a child (left=%d right=%d)", id, l, r);
-                rec_of[id] = (int)order.size();
-                entry[id] = rec_of[id];
-                order.push_back(id);
-                stack.push_back({r, depth + 1});  // left is numbered first (popped first)
-                stack.push_back({l, depth + 1});
-            }
-        }
-    }
-    const int need_stack = max_depth + 1;
-    if (need_stack > kMaxStack)
-        return set_error(RT_ERR_BAD_BVH, "rt_scene_create: tree depth %d overflows the reference's stack[256]", max_depth);
-
-    // ---- repack ------------------------------------------------------------------------------------------------
-    std::vector<float> rec(order.size() * 16, 0.0f);
-    for (size_t k = 0; k < order.size(); ++k) {
-        const NodeRec& nd = N[order[k]];
-        const int l = (int)nd.left, r = (int)nd.right;
-        float* q = &rec[k * 16];
-        q[0] = N[l].AA.x, q[1] = N[l].AA.y, q[2] = N[l].AA.z, q[3] = N[l].BB.x, q[4] = N[l].BB.y, q[5] = N[l].BB.z;
-        q[6] = N[r].AA.x, q[7] = N[r].AA.y, q[8] = N[r].AA.z, q[9] = N[r].BB.x, q[10] = N[r].BB.y, q[11] = N[r].BB.z;
-        memcpy(&q[12], &entry[l], 4);
-        memcpy(&q[13], &entry[r], 4);
-    }
-    std::vector<float> ttri((size_t)nT * 12);
-    for (int i = 0; i < nT; ++i) {
-        const TriRec& t = ((const TriRec*)tris)[i];
-        const vec3 Nn = normalize(cross(t.p2 - t.p1, t.p3 - t.p1));  // f5:180
-        float* q = &ttri[(size_t)i * 12];
-        q[0] = t.p1.x, q[1] = t.p1.y, q[2] = t.p1.z, q[3] = t.p2.x, q[4] = t.p2.y, q[5] = t.p2.z;
-        q[6] = t.p3.x, q[7] = t.p3.y, q[8] = t.p3.z, q[9] = Nn.x, q[10] = Nn.y, q[11] = Nn.z;
-    }
-    std::vector<float> dmat((size_t)nT * kDmatVec * 4, 0.0f);
-    for (int i = 0; i < nT; ++i) {
-        const rt_material& rm = ((const TriRec*)tris)[i].m;
-        Mat m;
-        m.emissive = v3(rm.emissive[0], rm.emissive[1], rm.emissive[2]);
-        m.baseColor = v3(rm.baseColor[0], rm.baseColor[1], rm.baseColor[2]);
-        m.subsurface = rm.subsurface, m.metallic = rm.metallic, m.specular = rm.specular;
-        m.specularTint = rm.specularTint, m.roughness = rm.roughness, m.anisotropic = rm.anisotropic;
-        m.sheen = rm.sheen, m.sheenTint = rm.sheenTint, m.clearcoat = rm.clearcoat;
-        m.clearcoatGloss = rm.clearcoatGloss;
-        const MatPre p = mat_precompute(m);
-        float* q = &dmat[(size_t)i * kDmatVec * 4];
-        q[16] = rm.baseColor[0], q[17] = rm.baseColor[1], q[18] = rm.baseColor[2], q[19] = rm.subsurface;
-        q[20] = rm.metallic, q[21] = rm.roughness, q[22] = rm.sheen, q[23] = rm.clearcoat;
-        q[0] = p.Cspec0.x, q[1] = p.Cspec0.y, q[2] = p.Cspec0.z, q[3] = p.Csheen.x, q[4] = p.Csheen.y, q[5] = p.Csheen.z;
-        q[6] = p.a2, q[7] = p.a2m1, q[8] = p.g1_a, q[9] = p.g1_a2, q[10] = p.g1_a2m1, q[11] = p.g1_k;
-        q[12] = p.p_d, q[13] = p.p_s, q[14] = p.p_c, q[15] = p.g1_lg;
-    }
-
-    // ---- culling margins (hitAABB_cull) ------------------------------------------------------------------------------
-    // Culling needs nested boxes.  A ray's margin scales with the scene extent; each box adds the shape term of the worst
-    // triangle below it: 2^-14 * longest edge / sin(smallest angle / 2) (the point S + d*t that hitTriangle accepts can lie
-    // that far beyond the tip of a needle-shaped triangle), kept per child in the node record.
-    // "Acceptable" triangles are those hitTriangle can ever accept (finite vertices, finite non-zero plane normal); the
-    // others never produce a hit and are ignored here.
-    double cull_extent = 0.0;
-    float cull_geo_max = 0.0f;
-    bool cull_ok = has_root;
-    std::vector<float> tri_margin(nT > 0 ? nT : 0, -1.0f);  // -1: not acceptable
+    // ---- everything derived from the caller's arrays, on the host (host_prep.cpp: all cores) ----------------------------
+    ScenePrep P;
     {
-        const float inf = __builtin_inff();
-        auto fin = [inf](float v) { return fabsf(v) < inf; };
-        for (int i = 0; i < nT; ++i) {
-            const float* q = &ttri[(size_t)i * 12];
-            bool ok = true;
-            for (int k = 0; k < 12; ++k) ok = ok && fin(q[k]);
-            ok = ok && (q[9] != 0.0f || q[10] != 0.0f || q[11] != 0.0f);
-            if (!ok) continue;
-            for (int k = 0; k < 9; ++k)
-                if (fabs((double)q[k]) > cull_extent) cull_extent = fabs((double)q[k]);
-            tri_margin[i] = tri_cull_margin(q);
-        }
-        // per node: the largest triangle margin below it (children come after their parent in `order`: walk it backwards)
-        std::vector<float> node_margin(nN > 0 ? nN : 0, 0.0f);
-        auto leaf_margin = [&](const NodeRec& cn) {
-            float m = 0.0f;
-            const int first = (int)cn.index, cnt = (int)cn.n;
-            for (int i = first; i < first + cnt; ++i)
-                if (tri_margin[i] > m) m = tri_margin[i];
-            return m;
-        };
-        for (size_t k = order.size(); k-- > 0;) {
-            const NodeRec& nd = N[order[k]];
-            const int ch[2] = {(int)nd.left, (int)nd.right};
-            float m = 0.0f;
-            for (int c = 0; c < 2; ++c) {
-                const NodeRec& cn = N[ch[c]];
-                if (cn.n > 0.0f) node_margin[ch[c]] = leaf_margin(cn);
-                if (node_margin[ch[c]] > m) m = node_margin[ch[c]];
-                memcpy(&rec[k * 16 + 14 + c], &node_margin[ch[c]], 4);
-                if (node_margin[ch[c]] < inf && node_margin[ch[c]] > cull_geo_max) cull_geo_max = node_margin[ch[c]];
-            }
-            node_margin[order[k]] = m;
-        }
-        // every box the traversal tests (all nodes but the root) must contain its children's boxes / its triangles
-        for (size_t k = 0; k < order.size() && cull_ok; ++k) {
-            const NodeRec& nd = N[order[k]];
-            const int ch[2] = {(int)nd.left, (int)nd.right};
-            for (int c = 0; c < 2 && cull_ok; ++c) {
-                const NodeRec& cn = N[ch[c]];
-                const float bb[6] = {cn.AA.x, cn.AA.y, cn.AA.z, cn.BB.x, cn.BB.y, cn.BB.z};
-                for (int j = 0; j < 6; ++j) {
-                    cull_ok = cull_ok && fin(bb[j]);
-                    if (fabs((double)bb[j]) > cull_extent) cull_extent = fabs((double)bb[j]);
-                }
-                if (order[k] != 1)  // (the root's own box is never tested, f5:268-291)
-                    cull_ok = cull_ok && cn.AA.x >= nd.AA.x && cn.AA.y >= nd.AA.y && cn.AA.z >= nd.AA.z && cn.BB.x <= nd.BB.x &&
-                              cn.BB.y <= nd.BB.y && cn.BB.z <= nd.BB.z;
-                if (cn.n > 0.0f) {  // leaf: its acceptable triangles lie inside its box
-                    const int first = (int)cn.index, cnt = (int)cn.n;
-                    for (int i = first; i < first + cnt && cull_ok; ++i) {
-                        if (tri_margin[i] < 0.0f) continue;
-                        const float* q = &ttri[(size_t)i * 12];
-                        for (int v = 0; v < 3; ++v)
-                            cull_ok = cull_ok && q[v * 3] >= cn.AA.x && q[v * 3] <= cn.BB.x && q[v * 3 + 1] >= cn.AA.y &&
-                                      q[v * 3 + 1] <= cn.BB.y && q[v * 3 + 2] >= cn.AA.z && q[v * 3 + 2] <= cn.BB.z;
-                    }
-                }
-            }
-        }
+        const int rc = prepare_scene(tris, nT, nodes, nN, hdr_map, hdr_cache, hdrW, hdrH, entry_mode, &P);
+        if (rc != RT_OK) return rc;
     }
-    float cull_eps = __builtin_inff();
-    if (cull_ok && cull_extent > 1e-10 && cull_extent < 1e30) cull_eps = nextafterf((float)(cull_extent / 8192.0), __builtin_inff());  // 2^-13 * extent
-
-    // ---- entry BVH (host_fastbvh.cpp): only where the reference tree is expensive to walk ---------------------------------
-    // Expected internal nodes a random line through the root box visits = sum over internal nodes of area / root area.
-    // The reference's INF = 114514 median splits (c5:500-502) push that into the hundreds on large scenes; a binned-SAH tree
-    // over the same triangles stays in the tens.  The path loop then walks the entry BVH first (conservative box test, real
-    // triangle test) to get a distance bound or to prove there is nothing to hit, and the reference tree only inside that
-    // bound (rt_device.hip, "phase").  Built when the reference tree costs > 32 and kept when at least twice as cheap.
-    std::vector<float> rec2, ttri2;
-    std::vector<int> map2, parentx;
-    std::vector<unsigned> leafx;
-    float climb_eps = 0.0f;
-    int root_entry2 = 0, depth2 = 0;
-    double cost_ref = 0.0, cost_entry = 0.0;
-    bool has_entry = false;
-    if (cull_eps < __builtin_inff() && !order.empty() && entry_mode >= 0 && (nT >= 1024 || entry_mode > 0)) {
-        auto area = [](const float* lo, const float* hi) {
-            const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
-            return (x < 0 || y < 0 || z < 0) ? 0.0 : 2.0 * (x * y + x * z + y * z);
-        };
-        const double root_area = area(&N[1].AA.x, &N[1].BB.x);
-        for (size_t k = 0; k < order.size(); ++k) cost_ref += area(&N[order[k]].AA.x, &N[order[k]].BB.x);
-        cost_ref = root_area > 0.0 ? cost_ref / root_area : 0.0;
-        if (cost_ref > 32.0 || entry_mode > 0) {
-            std::vector<float> tb((size_t)nT * 6);
-            std::vector<char> use(nT, 0);
-            for (int i = 0; i < nT; ++i) {
-                if (tri_margin[i] < 0.0f) continue;  // can never be hit
-                use[i] = 1;
-                const float* q = &ttri[(size_t)i * 12];
-                for (int c = 0; c < 3; ++c) {
-                    tb[(size_t)i * 6 + c] = fminf(q[c], fminf(q[3 + c], q[6 + c]));
-                    tb[(size_t)i * 6 + 3 + c] = fmaxf(q[c], fmaxf(q[3 + c], q[6 + c]));
-                }
-            }
-            std::vector<FastBvhNode> fn;
-            std::vector<int> perm;
-            const int root = build_fast_bvh(tb.data(), use.data(), nT, fn, perm);
-            if (root >= 0 && fn[root].count == 0) {
-                // records in pre-order (same 64-B layout as the reference tree's), triangles in leaf order
-                std::vector<int> rec_of2(fn.size(), -1), order2;
-                std::vector<std::pair<int, int>> stack2;
-                stack2.push_back({root, 0});
-                while (!stack2.empty()) {
-                    const int id = stack2.back().first, dep = stack2.back().second;
-                    stack2.pop_back();
-                    if (dep > depth2) depth2 = dep;
-                    if (fn[id].count > 0) continue;
-                    rec_of2[id] = (int)order2.size();
-                    order2.push_back(id);
-                    stack2.push_back({fn[id].right, dep + 1});
-                    stack2.push_back({fn[id].left, dep + 1});
-                }
-                const double ra2 = area(fn[root].AA, fn[root].BB);
-                for (int id : order2) cost_entry += area(fn[id].AA, fn[id].BB);
-                cost_entry = ra2 > 0.0 ? cost_entry / ra2 : 0.0;
-                if ((cost_entry * 2.0 < cost_ref || entry_mode > 0) && depth2 + 1 <= kMaxStack) {
-                    ttri2.resize(perm.size() * 12);
-                    for (size_t k = 0; k < perm.size(); ++k) memcpy(&ttri2[k * 12], &ttri[(size_t)perm[k] * 12], 48);
-                    rec2.assign(order2.size() * 16, 0.0f);
-                    std::vector<float> margin2(fn.size(), 0.0f);
-                    for (size_t k = order2.size(); k-- > 0;) {  // children come after their parent: walk backwards
-                        const FastBvhNode& nd = fn[order2[k]];
-                        const int ch[2] = {nd.left, nd.right};
-                        float m = 0.0f;
-                        float* q = &rec2[k * 16];
-                        for (int c = 0; c < 2; ++c) {
-                            const FastBvhNode& cn = fn[ch[c]];
-                            memcpy(q + 6 * c, cn.AA, 12), memcpy(q + 6 * c + 3, cn.BB, 12);
-                            int e;
-                            if (cn.count > 0) {
-                                float lm = 0.0f;
-                                for (int i = cn.first; i < cn.first + cn.count; ++i) lm = fmaxf(lm, tri_margin[perm[i]]);
-                                margin2[ch[c]] = lm;
-                                e = pack_leaf(cn.first, cn.count);
-                            } else {
-                                e = rec_of2[ch[c]];
-                            }
-                            memcpy(q + 12 + c, &e, 4);
-                            memcpy(q + 14 + c, &margin2[ch[c]], 4);
-                            m = fmaxf(m, margin2[ch[c]]);
-                        }
-                        margin2[order2[k]] = m;
-                    }
-                    root_entry2 = 0;  // record 0 = the root (pre-order)
-                    has_entry = true;
-                    map2 = perm;
-                    // where each reference box lives, for the climb from a triangle's leaf to the root (phase 1)
-                    leafx.assign(nT, 0u), parentx.assign(order.size(), -1);
-                    for (size_t k = 0; k < order.size(); ++k) {
-                        const NodeRec& nd = N[order[k]];
-                        const int ch[2] = {(int)nd.left, (int)nd.right};
-                        for (int c = 0; c < 2; ++c) {
-                            const NodeRec& cn = N[ch[c]];
-                            const int x = (int)(k << 1) | c;
-                            if (cn.n > 0.0f) {
-                                for (int i = (int)cn.index; i < (int)cn.index + (int)cn.n; ++i) leafx[i] = (unsigned)x;
-                            } else {
-                                parentx[rec_of[ch[c]]] = x;
-                            }
-                        }
-                    }
-                    // Short climbs.  Boxes nest, so going up from a triangle's leaf the triangle sits deeper and deeper inside:
-                    // from some level on it lies inside the box by more than mu = climb_eps + its shape margin on all six
-                    // sides.  An accepted hit point is within a fraction of that margin of the triangle (culling lemma), so it
-                    // is interior by ~mu, the slab parameters bracket t_W by mu / |d_i| — three orders of magnitude more than
-                    // their rounding error — and the reference's hitAABB returns > 0 for certain.  Only the levels below need
-                    // the explicit check; their number goes into bits 24..31 of leafx.  Valid for rays whose margin eps_ray
-                    // <= climb_eps = 4 x the scene part (origins within 3 scene extents); other rays climb to the root.
-                    climb_eps = 4.0f * cull_eps;
-                    for (int i = 0; i < nT; ++i) {
-                        if (tri_margin[i] < 0.0f) continue;
-                        const float* q = &ttri[(size_t)i * 12];
-                        double lo[3], hi[3];
-                        for (int c = 0; c < 3; ++c) {
-                            lo[c] = fmin((double)q[c], fmin((double)q[3 + c], (double)q[6 + c]));
-                            hi[c] = fmax((double)q[c], fmax((double)q[3 + c], (double)q[6 + c]));
-                        }
-                        const double mu = (double)climb_eps + (double)tri_margin[i];
-                        unsigned x = leafx[i];
-                        int level = 0;
-                        for (;;) {
-                            const float* b = &rec[(size_t)(x >> 1) * 16 + 6 * (x & 1u)];
-                            bool inside = true;
-                            for (int c = 0; c < 3; ++c) inside = inside && (lo[c] - (double)b[c] >= mu) && ((double)b[3 + c] - hi[c] >= mu);
-                            if (inside) break;
-                            ++level;
-                            const int up = parentx[x >> 1];
-                            if (up < 0) break;
-                            x = (unsigned)up;
-                        }
-                        leafx[i] |= (unsigned)(level < 255 ? level : 255) << 24;
-                    }
-                }
-            }
-        }
-    }
+    const bool has_root = P.has_root, has_entry = P.has_entry;
+    const int need_stack = P.need_stack, depth2 = P.depth2;
+    const float cull_eps = P.cull_eps, cull_geo_max = P.cull_geo_max, climb_eps = P.climb_eps;
+    const double cost_ref = P.cost_ref, cost_entry = P.cost_entry;
+    const int root_entry2 = P.root_entry2;
+    const RawBuf<float>&rec = P.rec, &ttri = P.ttri, &dmat = P.dmat, &rec2 = P.rec2, &ttri2 = P.ttri2;
+    const std::vector<int>&map2 = P.map2, &parentx = P.parentx;
+    const std::vector<unsigned>& leafx = P.leafx;
 
     rt_scene* s = new rt_scene();
     s->device = g_device;
@@ -1491,22 +1204,11 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
     }
     const size_t npx = (size_t)(hdr_map ? hdrW : 0) * (size_t)(hdr_map ? hdrH : 0);
     if (hdr_map) {
-        std::vector<float> tmp(npx * 4, 0.0f);
-        for (size_t i = 0; i < npx; ++i) {
-            tmp[i * 4] = hdr_map[i * 3], tmp[i * 4 + 1] = hdr_map[i * 3 + 1], tmp[i * 4 + 2] = hdr_map[i * 3 + 2];
-            tmp[i * 4 + 3] = hdr_cache ? hdr_cache[i * 3 + 2] : 0.0f;  // hdrCache's pdf channel (f5:651) at the same texel
-        }
         HIPCHK_S(hipMalloc(&s->d_hdr, npx * 16));
-        HIPCHK_S(hipMemcpy(s->d_hdr, tmp.data(), npx * 16, hipMemcpyHostToDevice));
+        HIPCHK_S(hipMemcpy(s->d_hdr, P.hdr4.data(), npx * 16, hipMemcpyHostToDevice));
         if (hdr_cache) {
-            // hdrCache reaches the device in two derived forms: its pdf channel in hdr.w (above) and, per texel, the direction
-            // SampleHdr computes from its (x, y) channels (f5:615-624)
-            for (size_t i = 0; i < npx; ++i) {
-                const vec3 L = hdrDirection(hdr_cache[i * 3], hdr_cache[i * 3 + 1]);
-                tmp[i * 4] = L.x, tmp[i * 4 + 1] = L.y, tmp[i * 4 + 2] = L.z;
-            }
             HIPCHK_S(hipMalloc(&s->d_cdir, npx * 16));
-            HIPCHK_S(hipMemcpy(s->d_cdir, tmp.data(), npx * 16, hipMemcpyHostToDevice));
+            HIPCHK_S(hipMemcpy(s->d_cdir, P.cdir4.data(), npx * 16, hipMemcpyHostToDevice));
         }
     }
 #undef HIPCHK_S
@@ -1518,7 +1220,7 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
     s->dev.cdir = (const float4*)s->d_cdir;
     s->dev.hdrW = hdrW, s->dev.hdrH = hdrH;
     s->dev.has_root = has_root ? 1 : 0;
-    s->dev.root_entry = has_root ? entry[1] : 0;
+    s->dev.root_entry = P.root_entry;
     s->dev.cull_eps = cull_eps;
     s->dev.nodes2 = (const float4*)s->d_nodes2;
     s->dev.ttri2 = (const float4*)s->d_ttri2;

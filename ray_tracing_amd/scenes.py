@@ -129,7 +129,7 @@ def cached_build(path: str, key: int, builder):
 
 
 def synthetic_scene_cached(cache_dir: str, n_objects: int = 64, subdiv: int = 32, seed: int = 0x5EED):
-    """synthetic_scene behind the on-disk cache: the 10 M-triangle build (90 s) is paid once."""
+    """synthetic_scene behind the on-disk cache: the 10 M-triangle build (8 s on 16 cores, 2.5 s of it numpy) is paid once."""
     from . import hash_fnv1a64
     key = hash_fnv1a64(np.array([n_objects, subdiv, seed, 8], np.int64), hash_fnv1a64(open(_m("quad.obj"), "rb").read()))
     path = os.path.join(cache_dir, f"synthetic_{n_objects}_{subdiv}_{seed:x}.rtsc")

@@ -4,11 +4,13 @@
 #include <stdlib.h>
 #include <unistd.h>
 #include <string.h>
+#include <math.h>
 
 #include <string>
 #include <vector>
 
 #include "../include/ray_tracing_amd.h"
+#include "../ray_tracing_amd/csrc/rt_host.h"  // prepare_scene: the host half of rt_scene_create (the device half is not linked here)
 
 #define CHECK(cond)                                                         \
     do {                                                                    \
@@ -57,6 +59,34 @@ int main(int argc, char** argv) {
                 CHECK(truncate(p.c_str(), 60) == 0);
                 CHECK(rt_scene_cache_load(p.c_str(), key, &t2, &a, &n2, &b) == RT_ERR_FORMAT);
                 remove(p.c_str());
+                // the host half of rt_scene_create: records, margins, entry BVH (forced) with its climb tables
+                for (int entry_mode : {0, 1, -1}) {
+                    rta::ScenePrep prep;
+                    CHECK(rta::prepare_scene(rt_mesh_data(mesh), nT, nodes, nN, nullptr, nullptr, 0, 0, entry_mode, &prep) == RT_OK);
+                    CHECK(prep.has_root && prep.ttri.size() == (size_t)nT * 12 && prep.has_entry == (entry_mode == 1));
+                    CHECK(!prep.has_entry || (prep.leafx.size() == (size_t)nT && prep.map2.size() == (size_t)nT));
+                }
+                // malformed trees must be refused (or rendered un-culled), never walked out of bounds
+                std::vector<float> bad(nodes, nodes + (size_t)nN * 12);
+                rta::ScenePrep prep;
+                bad[12 + 0] = (float)(nN + 5);  // root's left child out of range
+                CHECK(rta::prepare_scene(rt_mesh_data(mesh), nT, bad.data(), nN, nullptr, nullptr, 0, 0, 1, &prep) == RT_ERR_BAD_BVH);
+                bad[12 + 0] = 1.0f;             // the root is its own child
+                CHECK(rta::prepare_scene(rt_mesh_data(mesh), nT, bad.data(), nN, nullptr, nullptr, 0, 0, 1, &prep) == RT_ERR_BAD_BVH);
+                bad[12 + 0] = 2.5f;             // not an index
+                CHECK(rta::prepare_scene(rt_mesh_data(mesh), nT, bad.data(), nN, nullptr, nullptr, 0, 0, 1, &prep) == RT_ERR_BAD_BVH);
+                bad.assign(nodes, nodes + (size_t)nN * 12);
+                for (int k = 1; k < nN; ++k)
+                    if (bad[(size_t)k * 12 + 3] > 0.0f) {  // first leaf: its range runs past the triangle array
+                        bad[(size_t)k * 12 + 4] = (float)(nT - 1);
+                        bad[(size_t)k * 12 + 3] = 8.0f;
+                        break;
+                    }
+                CHECK(rta::prepare_scene(rt_mesh_data(mesh), nT, bad.data(), nN, nullptr, nullptr, 0, 0, 1, &prep) == RT_ERR_BAD_BVH);
+                bad.assign(nodes, nodes + (size_t)nN * 12);
+                bad[2 * 12 + 6] = NAN, bad[3 * 12 + 9] = -INFINITY;  // non-finite boxes: accepted, rendered without culling or entry BVH
+                CHECK(rta::prepare_scene(rt_mesh_data(mesh), nT, bad.data(), nN, nullptr, nullptr, 0, 0, 1, &prep) == RT_OK);
+                CHECK(!prep.has_entry && !(prep.cull_eps < INFINITY));
             }
             rt_free(nodes);
         }
@@ -94,6 +124,11 @@ int main(int argc, char** argv) {
     CHECK(rt_hdr_load((assets + "/HDR/peppermint_powerplant_4k.hdr").c_str(), &W, &H, &hdr) == RT_OK && W == 1024 && H == 512);
     std::vector<float> cache((size_t)W * H * 3);
     CHECK(rt_hdr_cache(hdr, W, H, cache.data()) == RT_OK);
+    {  // HDR texels + SampleHdr directions of the host preparation, on a scene without triangles
+        rta::ScenePrep prep;
+        CHECK(rta::prepare_scene(nullptr, 0, nullptr, 0, hdr, cache.data(), W, H, 0, &prep) == RT_OK);
+        CHECK(!prep.has_root && prep.hdr4.size() == (size_t)W * H * 4 && prep.cdir4.size() == (size_t)W * H * 4);
+    }
     std::vector<unsigned char> rgb8((size_t)W * H * 3);
     CHECK(rt_tonemap_rgb8(hdr, W, H, rgb8.data(), 1) == RT_OK);
     CHECK(rt_write_png((tmp + "/rt_sanitize.png").c_str(), W, H, rgb8.data(), 0) == RT_OK);

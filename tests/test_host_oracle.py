@@ -425,7 +425,7 @@ def test_scene_cache_round_trip_and_rejections(tmp_path):
     assert t2.tobytes() == np.ascontiguousarray(tris, np.float32).tobytes()
     assert n2.tobytes() == np.ascontiguousarray(nodes, np.float32).tobytes()
     raw = open(path, "rb").read()
-    assert len(raw) == 48 + t2.nbytes + n2.nbytes and raw[:8] == b"RTAMDSC1"  # header + the reference's arrays, nothing else
+    assert len(raw) == 48 + t2.nbytes + n2.nbytes and raw[:8] == b"RTAMDSC2"  # header + the reference's arrays, nothing else
     with pytest.raises(rt.RtError):  # stale: built from other inputs
         rt.scene_cache_load(path, key ^ 1)
     with pytest.raises(rt.RtError):  # missing
