@@ -29,6 +29,8 @@
 
 namespace rta {
 
+constexpr double kClimbDiv = 8.0;  // short climbs: mu = climb_eps / kClimbDiv + shape margin (see below)
+
 static int f2i_checked(float f, int* out) {
     if (!(f >= -1.0f && f < 16777216.0f)) return 0;
     const int i = (int)f;
@@ -37,46 +39,110 @@ static int f2i_checked(float f, int* out) {
     return 1;
 }
 
-// Writes the records of the entry BVH's subtree under internal node `id`, numbered in pre-order from `recno`; returns the
-// largest triangle margin below it (each record carries its two children's margins, as the reference tree's records do).
-struct EntryEmit {
+// The entry BVH reaches the device 4 wide: a walk on a scene that does not fit the caches is a chain of dependent memory
+// round trips (one per node visited), and a 4-wide node does the work of two binary levels in one.  The binary tree of
+// host_fastbvh.cpp is collapsed greedily (the child with the largest box is replaced by its own two children until there are
+// four, or only leaves are left).  A record is 128 bytes = two halves in the layout of the reference tree's records
+// (two boxes, two entries, two margins each), so the kernel tests children (0, 1) with the code it uses for the reference
+// tree and children (2, 3) with the same code again; a missing child has entry kNoChild.
+// measure(): per 4-wide node (named by the binary node it grew from) the number of 4-wide nodes in its subtree (records are
+// numbered in pre-order, so a child's number follows from the sizes of the subtrees before it), the deepest stack a walk can
+// need below it and the largest triangle margin below it.  emit(): writes the records.  Both as task-parallel recursions.
+struct EntryEmit4 {
     const FastBvhNode* fn;
     const int* perm;
     const float* tri_margin;
-    float* rec2;
-    float emit(int id, int recno) {
-        const FastBvhNode& nd = fn[id];
-        const int ch[2] = {nd.left, nd.right};
-        const int rn[2] = {recno + 1, recno + 1 + (fn[ch[0]].count > 0 ? 0 : fn[ch[0]].first)};
-        float cm[2] = {0.0f, 0.0f};
-        int ce[2];
-        for (int c = 0; c < 2; ++c) {
-            const FastBvhNode& cn = fn[ch[c]];
-            if (cn.count > 0) {
-                for (int i = cn.first; i < cn.first + cn.count; ++i) cm[c] = fmaxf(cm[c], tri_margin[perm[i]]);
-                ce[c] = pack_leaf(cn.first, cn.count);
+    int* cnt4;      // per binary node: 4-wide nodes in the subtree of the 4-wide node grown from it
+    float* margin;  // per binary node that is a 4-wide node: largest triangle margin below
+    float* rec2 = nullptr;
+
+    static double area(const FastBvhNode& n) {
+        const double x = (double)n.BB[0] - n.AA[0], y = (double)n.BB[1] - n.AA[1], z = (double)n.BB[2] - n.AA[2];
+        return (x < 0 || y < 0 || z < 0) ? 0.0 : 2.0 * (x * y + x * z + y * z);
+    }
+    int collapse(int id, int ch[4]) const {
+        int k = 2;
+        ch[0] = fn[id].left, ch[1] = fn[id].right;
+        while (k < 4) {
+            int pick = -1;
+            double best = -1.0;
+            for (int j = 0; j < k; ++j)
+                if (fn[ch[j]].count == 0 && area(fn[ch[j]]) > best) best = area(fn[ch[j]]), pick = j;
+            if (pick < 0) break;
+            const int c = ch[pick];
+            ch[pick] = fn[c].left, ch[k++] = fn[c].right;
+        }
+        return k;
+    }
+    float leaf_margin(const FastBvhNode& cn) const {
+        float m = 0.0f;
+        for (int i = cn.first; i < cn.first + cn.count; ++i) m = fmaxf(m, tri_margin[perm[i]]);
+        return m;
+    }
+    // returns the stack entries a walk below `id` can hold at once (its own pending children included)
+    int measure(int id) {
+        int ch[4];
+        const int k = collapse(id, ch);
+        int need[4] = {0, 0, 0, 0};
+        const bool par = fn[id].first >= 4096;  // (`first` of an internal binary node: internal nodes below it)
+        for (int j = 0; j < k; ++j) {
+            if (fn[ch[j]].count > 0) continue;
+            if (par) {
+#pragma omp task default(shared) firstprivate(j)
+                need[j] = measure(ch[j]);
             } else {
-                ce[c] = rn[c];
+                need[j] = measure(ch[j]);
             }
         }
-        const bool l_int = fn[ch[0]].count == 0, r_int = fn[ch[1]].count == 0;
-        if (l_int && r_int && nd.first >= 2048) {
-#pragma omp task default(shared)
-            cm[0] = emit(ch[0], rn[0]);
-            cm[1] = emit(ch[1], rn[1]);
 #pragma omp taskwait
-        } else {
-            if (l_int) cm[0] = emit(ch[0], rn[0]);
-            if (r_int) cm[1] = emit(ch[1], rn[1]);
+        int n4 = 1, deepest = 0;
+        float m = 0.0f;
+        for (int j = 0; j < k; ++j) {
+            const FastBvhNode& cn = fn[ch[j]];
+            if (cn.count > 0) {
+                m = fmaxf(m, leaf_margin(cn));
+            } else {
+                n4 += cnt4[ch[j]], m = fmaxf(m, margin[ch[j]]);
+                if (need[j] > deepest) deepest = need[j];
+            }
         }
-        float* q = rec2 + (size_t)recno * 16;
-        for (int c = 0; c < 2; ++c) {
-            const FastBvhNode& cn = fn[ch[c]];
-            memcpy(q + 6 * c, cn.AA, 12), memcpy(q + 6 * c + 3, cn.BB, 12);
-            memcpy(q + 12 + c, &ce[c], 4);
-            memcpy(q + 14 + c, &cm[c], 4);
+        cnt4[id] = n4, margin[id] = m;
+        return (k - 1) + deepest;  // while one child's subtree is walked, the other k - 1 may be on the stack
+    }
+    void emit(int id, int recno) {
+        int ch[4];
+        const int k = collapse(id, ch);
+        float* q = rec2 + (size_t)recno * 32;
+        int next = recno + 1;
+        const bool par = fn[id].first >= 4096;
+        for (int j = 0; j < 4; ++j) {
+            float* h = q + 16 * (j >> 1);  // the half record of children (0, 1) or (2, 3)
+            const int c = j & 1;
+            int e = kNoChild;
+            float m = 0.0f;
+            if (j < k) {
+                const FastBvhNode& cn = fn[ch[j]];
+                memcpy(h + 6 * c, cn.AA, 12), memcpy(h + 6 * c + 3, cn.BB, 12);
+                if (cn.count > 0) {
+                    e = pack_leaf(cn.first, cn.count), m = leaf_margin(cn);
+                } else {
+                    e = next, m = margin[ch[j]];
+                    const int child = ch[j], child_rec = next;
+                    next += cnt4[ch[j]];
+                    if (par) {
+#pragma omp task default(shared) firstprivate(child, child_rec)
+                        emit(child, child_rec);
+                    } else {
+                        emit(child, child_rec);
+                    }
+                }
+            } else {
+                for (int t = 0; t < 6; ++t) h[6 * c + t] = 0.0f;
+            }
+            memcpy(h + 12 + c, &e, 4);
+            memcpy(h + 14 + c, &m, 4);
         }
-        return fmaxf(cm[0], cm[1]);
+#pragma omp taskwait
     }
 };
 
@@ -261,7 +327,7 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
     std::vector<int> map2, parentx;
     std::vector<unsigned> leafx;
     float climb_eps = 0.0f;
-    int root_entry2 = 0, depth2 = 0;
+    int root_entry2 = 0, depth2 = 0, stack2 = 0;  // stack2: stack entries a walk of the 4-wide entry BVH can hold
     double cost_ref = 0.0, cost_entry = 0.0;
     bool has_entry = false;
     if (cull_eps < __builtin_inff() && !order.empty() && entry_mode >= 0 && (nT >= 1024 || entry_mode > 0)) {
@@ -297,18 +363,26 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
                 const double ra2 = area(fn[root].AA, fn[root].BB);
                 cost_entry = ra2 > 0.0 ? sum_area / ra2 : 0.0;
                 if ((cost_entry * 2.0 < cost_ref || entry_mode > 0) && depth2 + 1 <= kMaxStack) {
+                    // 4-wide records in pre-order (EntryEmit4 above)
+                    std::vector<int> cnt4((size_t)n_fn, 0);
+                    RawBuf<float> margin4;
+                    margin4.alloc((size_t)n_fn);
+                    EntryEmit4 em{fn.data(), perm.data(), tri_margin.data(), cnt4.data(), margin4.data()};
+                    int need4 = 0;
+#pragma omp parallel
+#pragma omp single
+                    need4 = em.measure(root);
+                    if (need4 + 1 <= kMaxStack) {  // (always, below 2^24 triangles; otherwise the reference tree serves alone)
+                    stack2 = need4 + 1;
                     ttri2.alloc(perm.size() * 12);
 #pragma omp parallel for schedule(static)
                     for (size_t k = 0; k < perm.size(); ++k) memcpy(&ttri2[k * 12], &ttri[(size_t)perm[k] * 12], 48);
                     PREP_MARK("  entry triangles");
-                    // records in pre-order (same 64-B layout as the reference tree's): an internal node's `first` holds the
-                    // number of internal nodes of its subtree, so the record numbers follow top-down — the node itself, then
-                    // its left subtree, then its right one — and subtrees are emitted as parallel tasks
-                    rec2.alloc((size_t)fn[root].first * 16);
-                    EntryEmit em{fn.data(), perm.data(), tri_margin.data(), rec2.data()};
+                    rec2.alloc((size_t)cnt4[root] * 32);
+                    em.rec2 = rec2.data();
 #pragma omp parallel
 #pragma omp single
-                    (void)em.emit(root, 0);
+                    em.emit(root, 0);
                     PREP_MARK("  entry records + margins");
                     root_entry2 = 0;  // record 0 = the root (pre-order)
                     has_entry = true;
@@ -330,12 +404,14 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
                         }
                     }
                     // Short climbs.  Boxes nest, so going up from a triangle's leaf the triangle sits deeper and deeper inside:
-                    // from some level on it lies inside the box by more than mu = climb_eps + its shape margin on all six
-                    // sides.  An accepted hit point is within a fraction of that margin of the triangle (culling lemma), so it
-                    // is interior by ~mu, the slab parameters bracket t_W by mu / |d_i| — three orders of magnitude more than
-                    // their rounding error — and the reference's hitAABB returns > 0 for certain.  Only the levels below need
-                    // the explicit check; their number goes into bits 24..31 of leafx.  Valid for rays whose margin eps_ray
-                    // <= climb_eps = 4 x the scene part (origins within 3 scene extents); other rays climb to the root.
+                    // from some level on it lies inside the box by more than mu on all six sides.  An accepted hit point P is
+                    // within delta <= 46u*M + 21u*L/sin(theta) of the triangle (culling lemma; u = 2^-24,
+                    // M = max|S_i| + extent), so P is interior by mu - delta; the reference's slab parameters are off by at most
+                    // 6u*M/|d_i|, so its hitAABB returns > 0 for certain once mu - delta > 6u*M.  mu = climb_eps / 8 + the
+                    // triangle's shape margin = 256u*M_max + 1024u*L/sin(theta/2): five times what is needed for every ray with
+                    // M <= M_max = 4 * extent, i.e. eps_ray <= climb_eps = 4 x the scene part (origins within 3 scene extents);
+                    // other rays climb to the root.  Only the levels below need the explicit check; their number goes into
+                    // bits 24..31 of leafx.
                     PREP_MARK("  leafx / parentx");
                     climb_eps = 4.0f * cull_eps;
 #pragma omp parallel for schedule(dynamic, 4096)
@@ -347,7 +423,7 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
                             lo[c] = fmin((double)q[c], fmin((double)q[3 + c], (double)q[6 + c]));
                             hi[c] = fmax((double)q[c], fmax((double)q[3 + c], (double)q[6 + c]));
                         }
-                        const double mu = (double)climb_eps + (double)tri_margin[i];
+                        const double mu = (double)climb_eps / kClimbDiv + (double)tri_margin[i];
                         unsigned x = leafx[i];
                         int level = 0;
                         for (;;) {
@@ -361,6 +437,16 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
                             x = (unsigned)up;
                         }
                         leafx[i] |= (unsigned)(level < 255 ? level : 255) << 24;
+                    }
+#ifdef RT_PREP_TIMING
+                    {
+                        double sum = 0;
+                        long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        for (int i = 0; i < nT; ++i) sum += leafx[i] >> 24, hist[(leafx[i] >> 24) < 7 ? (leafx[i] >> 24) : 7]++;
+                        fprintf(stderr, "prepare_scene: explicit climb levels per triangle: mean %.2f; 0:%ld 1:%ld 2:%ld 3:%ld 4:%ld 5:%ld 6:%ld 7+:%ld; 4-wide records %zu, stack %d\n",
+                                sum / (nT > 0 ? nT : 1), hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], rec2.size() / 32, stack2);
+                    }
+#endif
                     }
                 }
             }
@@ -396,7 +482,7 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
     out->rec.swap(rec), out->ttri.swap(ttri), out->dmat.swap(dmat);
     out->cull_eps = cull_eps, out->cull_geo_max = cull_geo_max;
     out->rec2.swap(rec2), out->ttri2.swap(ttri2), out->map2.swap(map2), out->parentx.swap(parentx), out->leafx.swap(leafx);
-    out->climb_eps = climb_eps, out->root_entry2 = root_entry2, out->depth2 = depth2;
+    out->climb_eps = climb_eps, out->root_entry2 = root_entry2, out->stack2 = stack2;
     out->cost_ref = cost_ref, out->cost_entry = cost_entry, out->has_entry = has_entry;
     return RT_OK;
 }

@@ -78,7 +78,7 @@ struct DevScene {
     int has_root;
     float cull_eps;       // scene part of a ray's culling margin (see hitAABB_cull); +inf = this scene is never culled
     float cull_geo_max;   // largest finite per-box margin of the node records
-    const float4* nodes2; // entry BVH: node records (same layout as `nodes`) ...
+    const float4* nodes2; // entry BVH, 4 wide: 8 x float4 per node = two halves in the layout of `nodes` (children 0,1 | 2,3; entry kNoChild = none) ...
     const float4* ttri2;  // ... and its triangles (same layout as `ttri`), in its own leaf order
     const int* map2;      // entry-BVH triangle -> index in the caller's order
     const unsigned* leafx; // per triangle (caller's order): where its leaf's box lives = (record << 1 | side), 24 bits; bits 24..31: how
@@ -710,10 +710,15 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             // ---- one internal node (f5:282-307) ------------------------------------------------------------------
             if (op == OP_INT) {
                 if (STATS) st.internal++;
-                const float4* nb = (ENTRY && phase == 0) ? sc.nodes2 : sc.nodes;
+                // phase 0 walks the 4-wide entry BVH: a record is two halves in the reference records' layout — children (0, 1)
+                // in q0..q3, tested by the code below like the reference tree's two children, children (2, 3) in q4..q7
+                const bool wide = ENTRY && phase == 0;
                 const int rec = (ENTRY && phase == 1) ? (cur >> 1) : cur;  // phase 1: cur = (record << 1 | side) of the box to check
-                const float4 q0 = nb[rec * 4 + 0], q1 = nb[rec * 4 + 1], q2 = nb[rec * 4 + 2];
-                const float4 q3 = nb[rec * 4 + 3];  // the two child entries, the two children's culling margins
+                const float4* nb = wide ? sc.nodes2 + rec * 8 : sc.nodes + rec * 4;
+                const float4 q0 = nb[0], q1 = nb[1], q2 = nb[2];
+                const float4 q3 = nb[3];  // the two child entries, the two children's culling margins
+                float4 q4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q5 = q4, q6 = q4, q7 = q4;
+                if (wide) q4 = nb[4], q5 = nb[5], q6 = nb[6], q7 = nb[7];  // (issued with the first half: one round trip)
                 const vec3 lAA = v3(q0.x, q0.y, q0.z), lBB = v3(q0.w, q1.x, q1.y);
                 const vec3 rAA = v3(q1.z, q1.w, q2.x), rBB = v3(q2.y, q2.z, q2.w);
                 // a child whose inflated box starts beyond the closest hit so far cannot change the result: skip it
@@ -753,6 +758,37 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                         op = OP_H, sp = 0;  // W at t_W is the reference's answer
                     } else if (refuted) {
                         phase = 2, sp = -1, op = OP_END;  // the reference never reaches W's leaf: its own walk decides (sp = -1: restart)
+                    }
+                } else if (wide) {
+                    // the other two children, then all four in order of entry distance: the nearest is walked next, the
+                    // others wait on the stack, nearest on top (the entry BVH never decides a result, only the order)
+                    float c3, c4, e3, e4;
+                    (void)hitAABB_cull(S, invdir, v3(q4.x, q4.y, q4.z), v3(q4.w, q5.x, q5.y), ceps, q7.z, &c3, &e3);
+                    (void)hitAABB_cull(S, invdir, v3(q5.z, q5.w, q6.x), v3(q6.y, q6.z, q6.w), ceps, q7.w, &c4, &e4);
+                    int n0 = le, n1 = re, n2 = __float_as_int(q7.x), n3 = __float_as_int(q7.y);
+                    float k0 = d1 > 0.0f ? d1 : INF_, k1 = d2 > 0.0f ? d2 : INF_;  // (children 0 and 1 always exist)
+                    float k2 = (c3 <= e3 && e3 >= 0.0f && c3 <= best && n2 != kNoChild) ? __builtin_fmaxf(c3, 1e-30f) : INF_;
+                    float k3 = (c4 <= e4 && e4 >= 0.0f && c4 <= best && n3 != kNoChild) ? __builtin_fmaxf(c4, 1e-30f) : INF_;
+#define RT_CSWAP(ka, kb, na, nb_)                    \
+    {                                                \
+        const bool sw_ = kb < ka;                    \
+        const float tk_ = sw_ ? kb : ka;             \
+        kb = sw_ ? ka : kb, ka = tk_;                \
+        const int tn_ = sw_ ? nb_ : na;              \
+        nb_ = sw_ ? na : nb_, na = tn_;              \
+    }
+                    RT_CSWAP(k0, k1, n0, n1) RT_CSWAP(k2, k3, n2, n3) RT_CSWAP(k0, k2, n0, n2) RT_CSWAP(k1, k3, n1, n3) RT_CSWAP(k1, k2, n1, n2)
+#undef RT_CSWAP
+                    if (k3 < INF_) wstack_push<SPILL>(stk_lds, stk_spill, stk_stride, sp++, n3);
+                    if (k2 < INF_) wstack_push<SPILL>(stk_lds, stk_spill, stk_stride, sp++, n2);
+                    if (k1 < INF_) wstack_push<SPILL>(stk_lds, stk_spill, stk_stride, sp++, n1);
+                    if (k0 < INF_) {
+                        cur = n0;
+                    } else if (sp == 0) {
+                        op = OP_END;
+                        popped = true;
+                    } else {
+                        cur = wstack_pop<SPILL>(stk_lds, stk_spill, stk_stride, --sp);
                     }
                 } else if (d1 > 0.0f && d2 > 0.0f) {
                     if (d1 < d2) {  // left first
@@ -1037,7 +1073,8 @@ using namespace rta;
 struct rt_scene {
     int device = 0;
     int nT = 0, nN = 0;
-    int max_stack = 0;  // stack entries the deepest traversal can hold
+    int max_stack = 0;  // stack entries the deepest traversal can hold (reference tree or 4-wide entry BVH)
+    int ref_depth = 0;  // levels below the root of the reference tree
     DevScene dev{};
     void* d_ttri = nullptr;
     void* d_dmat = nullptr;
@@ -1136,7 +1173,7 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
         if (rc != RT_OK) return rc;
     }
     const bool has_root = P.has_root, has_entry = P.has_entry;
-    const int need_stack = P.need_stack, depth2 = P.depth2;
+    const int need_stack = P.need_stack, stack2 = P.stack2;
     const float cull_eps = P.cull_eps, cull_geo_max = P.cull_geo_max, climb_eps = P.climb_eps;
     const double cost_ref = P.cost_ref, cost_entry = P.cost_entry;
     const int root_entry2 = P.root_entry2;
@@ -1148,7 +1185,8 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
     s->device = g_device;
     s->cull_eps = cull_eps;
     s->dev.cull_geo_max = cull_geo_max;
-    s->nT = nT, s->nN = nN, s->max_stack = has_entry && depth2 + 1 > need_stack ? depth2 + 1 : need_stack;
+    s->nT = nT, s->nN = nN, s->max_stack = has_entry && stack2 > need_stack ? stack2 : need_stack;
+    s->ref_depth = need_stack - 1;
     s->cost_ref = (float)cost_ref, s->cost_entry = (float)cost_entry, s->has_entry = has_entry;
     auto fail = [&](int rc) {
         rt_scene_destroy(s);
@@ -1517,7 +1555,7 @@ int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
 int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
     if (!s || !out) return set_error(RT_ERR_INVALID_ARG, "rt_scene_get_info: NULL argument");
     out->n_triangles = s->nT, out->n_nodes = s->nN;
-    out->bvh_depth = s->max_stack - 1;
+    out->bvh_depth = s->ref_depth;
     out->stack_spill = s->max_stack > kLdsDepth ? 1 : 0;
     out->cull_enabled = (s->dev.cull_eps < __builtin_inff()) ? 1 : 0;
     out->cull_eps = s->cull_eps;

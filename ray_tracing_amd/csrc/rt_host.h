@@ -41,6 +41,7 @@ struct FastBvhNode {
 constexpr int kMaxStack = 256;  // int stack[256], f5:265
 constexpr int kDmatVec = 6;     // float4s per triangle in `dmat`: MatPre (4) + the material fields chapter 5's BRDF reads per evaluation (2)
 // a leaf as a traversal entry: sign bit | (n - 1) << 24 | first triangle
+constexpr int kNoChild = 0x7fffffff;  // entry of a missing child in a 4-wide entry-BVH record
 inline int pack_leaf(int index, int n) { return (int)(0x80000000u | ((unsigned)(n - 1) << 24) | (unsigned)index); }
 template <class T>
 struct RawBuf {  // an array that is NOT zero-filled on allocation (hundreds of MB at 10 M triangles, each written once by parallel loops)
@@ -62,11 +63,11 @@ struct ScenePrep {
     int need_stack = 0, root_entry = 0;
     RawBuf<float> rec, ttri, dmat;           // node records (16 floats), triangle records (12), material tables (kDmatVec * 4)
     float cull_eps = 0.0f, cull_geo_max = 0.0f;
-    RawBuf<float> rec2, ttri2;               // entry BVH: records, triangles in its leaf order
+    RawBuf<float> rec2, ttri2;               // entry BVH: 4-wide records (32 floats), triangles in its leaf order
     std::vector<int> map2, parentx;          // entry-BVH triangle -> caller's index; reference record -> (parent record << 1 | side)
     std::vector<unsigned> leafx;             // per triangle: (record << 1 | side) of its reference leaf, explicit climb levels in bits 24..31
     float climb_eps = 0.0f;
-    int root_entry2 = 0, depth2 = 0;
+    int root_entry2 = 0, stack2 = 0;         // stack2: stack entries a walk of the entry BVH can hold
     double cost_ref = 0.0, cost_entry = 0.0;
     bool has_entry = false;
     RawBuf<float> hdr4, cdir4;               // HDR texels (rgb, cache pdf); SampleHdr directions per cache texel

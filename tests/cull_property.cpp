@@ -108,10 +108,10 @@ int main(int argc, char** argv) {
             ++ineligible;  // never culled
             continue;
         }
-        // ---- short climb: a box that contains the triangle with a margin of mu = 4 * scene margin + shape
+        // ---- short climb: a box that contains the triangle with a margin of mu = scene margin / 2 + shape
         // margin on all six sides passes the REFERENCE's own box test for this ray, for certain (rays with eps_ray <= 4 * scene) ----
         if (eps_ray <= 4.0f * scene_eps) {
-            const float mu = 4.0f * scene_eps + eps_box;
+            const float mu = 0.5f * scene_eps + eps_box;  // = climb_eps / 8 + shape margin (host_prep.cpp)
             vec3 A = min3(p1, min3(p2, p3)), B = max3(p1, max3(p2, p3));
             for (int rep = 0; rep < 3; ++rep) {
                 const float g = mu * (1.0f + (float)(rep * rep) * (float)U(gen) * 50.0f);

@@ -1,10 +1,11 @@
-"""Sweeps rt_tuning on config 5 (1080p, mode 5) and prints Mpaths/s per setting."""
+"""Sweeps rt_tuning on config 5 (1080p, mode 5) — or, with --syn, on the 10 M-triangle synthetic scene — and prints Mpaths/s per setting."""
 import itertools, os, sys, time
+SYN = "--syn" in sys.argv
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 import ray_tracing_amd as rt
 from ray_tracing_amd import scenes
-t, n = scenes.chap5_scene()
+t, n = scenes.synthetic_scene_cached("/tmp", 256, 100) if SYN else scenes.chap5_scene()
 hdr, cache = scenes.hdr_and_cache()
 sc = rt.Scene(t, n, hdr, cache, device=0)
 eye, cam = rt.camera(0.0, 20.0, 4.0)
@@ -22,6 +23,17 @@ def run(spp, **kw):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     print(f"{kw} spp {spp}: {W * H * spp / dt / 1e6:8.1f} Mpaths/s", flush=True)
+if SYN:
+    run(4)
+    for ll in (4, 12, 16, 24, 32, 48):
+        run(4, leaf_lanes=ll)
+    for sl in (24, 32, 40, 56, 64):
+        run(4, shade_lanes=sl)
+    for wb in (1000, 2000, 8000, 16000, 64000):
+        run(4, wait_budget=wb)
+    for ll, sl in ((16, 32), (24, 32), (32, 32), (16, 56), (24, 56), (32, 56)):
+        run(4, leaf_lanes=ll, shade_lanes=sl)
+    sys.exit(0)
 run(32)
 for sl in (32, 40, 56, 64):
     run(32, shade_lanes=sl)
