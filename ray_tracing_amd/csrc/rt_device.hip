@@ -717,8 +717,6 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 const float4* nb = wide ? sc.nodes2 + rec * 8 : sc.nodes + rec * 4;
                 const float4 q0 = nb[0], q1 = nb[1], q2 = nb[2];
                 const float4 q3 = nb[3];  // the two child entries, the two children's culling margins
-                float4 q4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q5 = q4, q6 = q4, q7 = q4;
-                if (wide) q4 = nb[4], q5 = nb[5], q6 = nb[6], q7 = nb[7];  // (issued with the first half: one round trip)
                 const vec3 lAA = v3(q0.x, q0.y, q0.z), lBB = v3(q0.w, q1.x, q1.y);
                 const vec3 rAA = v3(q1.z, q1.w, q2.x), rBB = v3(q2.y, q2.z, q2.w);
                 // a child whose inflated box starts beyond the closest hit so far cannot change the result: skip it
@@ -762,6 +760,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 } else if (wide) {
                     // the other two children, then all four in order of entry distance: the nearest is walked next, the
                     // others wait on the stack, nearest on top (the entry BVH never decides a result, only the order)
+                    // (a record is one 128-byte line: the second half is an L1 hit by now, and loading it here keeps 16
+                    // registers free during the first half's tests)
+                    const float4 q4 = nb[4], q5 = nb[5], q6 = nb[6], q7 = nb[7];
                     float c3, c4, e3, e4;
                     (void)hitAABB_cull(S, invdir, v3(q4.x, q4.y, q4.z), v3(q4.w, q5.x, q5.y), ceps, q7.z, &c3, &e3);
                     (void)hitAABB_cull(S, invdir, v3(q5.z, q5.w, q6.x), v3(q6.y, q6.z, q6.w), ceps, q7.w, &c4, &e4);

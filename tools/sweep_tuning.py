@@ -24,15 +24,27 @@ def run(spp, **kw):
     dt = (time.perf_counter() - t0) / 3
     print(f"{kw} spp {spp}: {W * H * spp / dt / 1e6:8.1f} Mpaths/s", flush=True)
 if SYN:
-    run(4)
-    for ll in (4, 12, 16, 24, 32, 48):
-        run(4, leaf_lanes=ll)
-    for sl in (24, 32, 40, 56, 64):
-        run(4, shade_lanes=sl)
-    for wb in (1000, 2000, 8000, 16000, 64000):
-        run(4, wait_budget=wb)
-    for ll, sl in ((16, 32), (24, 32), (32, 32), (16, 56), (24, 56), (32, 56)):
-        run(4, leaf_lanes=ll, shade_lanes=sl)
+    def runk(**kw):  # kernel time (HIP events inside the library), launches of 8 frames: not overlapped
+        sc.set_tuning()
+        sc.set_tuning(**kw)
+        sc.render_device(d, 0, 8, acc.data_ptr(), st); torch.cuda.synchronize()
+        rt.kernel_time_ms(reset=True)
+        for i in range(3):
+            sc.render_device(d, (i + 1) * 8, 8, acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        ms, n = rt.kernel_time_ms(reset=True)
+        print(f"{str(kw):60s} kernel {ms:8.2f} ms  {W * H * 8 / ms / 1e3:8.1f} Mpaths/s", flush=True)
+    runk()
+    runk()
+    for sl in (16, 24, 32, 40, 56):
+        runk(shade_lanes=sl)
+    for ll in (4, 12, 16, 20):
+        runk(leaf_lanes=ll)
+    for wb in (500, 1000, 2000, 16000):
+        runk(wait_budget=wb)
+    for ll, sl in ((12, 24), (12, 32), (16, 24), (16, 32), (12, 40)):
+        runk(leaf_lanes=ll, shade_lanes=sl)
+    runk()
     sys.exit(0)
 run(32)
 for sl in (32, 40, 56, 64):
