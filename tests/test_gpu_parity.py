@@ -250,6 +250,41 @@ def test_deep_tree_spills_stack_exactly(hdr_pair):
         assert sc5.render_stats(d5, 1, F) == ost
 
 
+def test_entry_bvh_walk_spills_its_stack_exactly(hdr_pair):
+    """A deck of 36 000 parallel cards seen face-on: every box of the 4-wide entry BVH lies on the ray, so the first descent leaves
+    three siblings on the stack per level — 21 entries, past the 18 kept in LDS — and the entry walk (render_kernel<5, *, SPILL,
+    ENTRY>) runs through the global spill path; image and reference-walk statistics still equal the oracle's."""
+    hdr, cache = hdr_pair
+    n_cards = 36000
+    k = np.arange(n_cards, dtype=np.float64)
+    z = -0.6 + 0.6 * k / n_cards
+    ang = 0.37 * k
+    c, s_ = np.cos(ang), np.sin(ang)
+    half = 0.9 + 0.05 * np.sin(1.7 * k)
+    corners = np.stack([np.stack([half * (c * sx - s_ * sy), half * (s_ * sx + c * sy), z], -1) for sx, sy in ((-1, -1), (1, -1), (1, 1), (-1, 1))], 1)
+    tris = np.zeros((2 * n_cards, 36), np.float32)
+    for t, (i0, i1, i2) in enumerate(((0, 1, 2), (0, 2, 3))):
+        tris[t::2, 0:3], tris[t::2, 3:6], tris[t::2, 6:9] = corners[:, i0], corners[:, i1], corners[:, i2]
+    tris[:, 9:18] = np.tile(np.array([0, 0, 1], np.float32), 3)
+    tris[:, 18:36] = rt.Material(baseColor=(0.7, 0.6, 0.5), roughness=0.4).as_array()
+    mesh = rt.Mesh()
+    mesh.append(tris)
+    nodes = mesh.buildBVHwithSAH(8)
+    tris = mesh.triangles()
+    sc = rt.Scene(tris, nodes, hdr, cache, entry_bvh=1)
+    info = sc.info()
+    assert info.entry_bvh == 1 and info.stack_spill == 1
+    eye = np.array([0.02, -0.01, 2.0], np.float32)
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    d = rt.make_desc(20, 12, mode=5, eye=eye)
+    img = sc.render(d, 0, 2)
+    ref, ost = O.render(tris, nodes, hdr, cache, 20, 12, 5, eye, ident, 0, 2)
+    _assert_images_equal(img, ref, "deck of cards through the entry BVH's spill path")
+    assert sc.render_stats(d, 0, 2) == ost
+    ex = sc.render_stats(d, 0, 2, executed=True)
+    assert ex["internal_nodes"] < ost["internal_nodes"] // 4  # the walk that ran visits a fraction of the deck
+
+
 def test_mode5_rejects_more_bounces_than_the_sobol_table_holds(scene_small, hdr_pair):
     """f5:339 holds 8 Sobol dimensions = 4 bounces (f5:883, 949); a larger max_bounce would index past the table."""
     tris, nodes = scene_small
