@@ -717,6 +717,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 const float4* nb = wide ? sc.nodes2 + rec * 8 : sc.nodes + rec * 4;
                 const float4 q0 = nb[0], q1 = nb[1], q2 = nb[2];
                 const float4 q3 = nb[3];  // the two child entries, the two children's culling margins
+                int up = -1;  // phase 1: where the box above this one lives — requested with the record, not after its test
+                if (ENTRY && phase == 1) up = sc.parentx[rec];
                 const vec3 lAA = v3(q0.x, q0.y, q0.z), lBB = v3(q0.w, q1.x, q1.y);
                 const vec3 rAA = v3(q1.z, q1.w, q2.x), rBB = v3(q2.y, q2.z, q2.w);
                 // a child whose inflated box starts beyond the closest hit so far cannot change the result: skip it
@@ -730,7 +732,6 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     // no operand is NaN and d1 / d2 are the ternary form's values)
                     const float dv = (cur & 1) ? d2 : d1;
                     if (dv > 0.0f) {
-                        const int up = sc.parentx[rec];
                         if (sp != 255) --sp;  // (sp is free during the climb: the explicit checks still to do)
                         if (up < 0 || sp == 0) verified = true; else cur = up;
                     } else {
