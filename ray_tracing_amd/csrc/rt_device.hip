@@ -1050,6 +1050,7 @@ static void remember_launch(const TimedLaunch& tl) {
 }
 static thread_local int g_device = -1;
 static int scratch_address(int device, unsigned char** out);
+static int slot_streams(int device, hipStream_t out[2]);
 
 // Makes the scene's device current for the duration of an entry point and restores the caller's afterwards.
 struct DeviceGuard {
@@ -1140,7 +1141,6 @@ void rt_scene_destroy(rt_scene* s) {
         (void)hipFree(sl.d_spill), (void)hipFree(sl.d_samples), (void)hipFree(sl.d_queue), (void)hipFree(sl.d_sobol);
         if (sl.render_done) (void)hipEventDestroy(sl.render_done);
         if (sl.fold_done) (void)hipEventDestroy(sl.fold_done);
-        if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
     delete s;
 }
@@ -1204,17 +1204,18 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
     HIPCHK_S(hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, s->device));
     HIPCHK_S(hipMalloc((void**)&s->d_clk, 64));
     HIPCHK_S(hipMemset(s->d_clk, 0, 64));
-    // The two slots' streams get different priorities: the runtime keeps separate hardware-queue pools per priority, so the
-    // two can never be mapped onto one hardware queue (GPU_MAX_HW_QUEUES is 4 per process and streams share queues; two
-    // equal-priority streams that land on the same queue would run their kernels one after the other — observed when other
-    // scenes had created streams before).
-    int prio_least = 0, prio_greatest = 0;
-    HIPCHK_S(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    // The two slots' streams are shared by all scenes on a device (slot_streams below): a process gets one low- and one
+    // high-priority stream per device however many scenes it creates.
+    hipStream_t shared[2] = {nullptr, nullptr};
+    {
+        const int rc = slot_streams(s->device, shared);
+        if (rc != RT_OK) return fail(rc);
+    }
     int slot_no = 0;
     for (auto& sl : s->slot) {
         HIPCHK_S(hipMalloc((void**)&sl.d_queue, 8 * 16 * sizeof(unsigned)));
         HIPCHK_S(hipMalloc((void**)&sl.d_sobol, (size_t)kMaxLaunchFrames * 4 * sizeof(float2)));
-        HIPCHK_S(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, slot_no++ == 0 ? prio_least : prio_greatest));
+        sl.stream = shared[slot_no++];
         HIPCHK_S(hipEventCreateWithFlags(&sl.render_done, hipEventDisableTiming));
         HIPCHK_S(hipEventCreateWithFlags(&sl.fold_done, hipEventDisableTiming));
     }
@@ -1506,6 +1507,35 @@ static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 64;
 static std::mutex g_scratch_mutex;
 static unsigned char* g_scratch_ptr[kMaxDevices];  // per device: the address of ITS copy of `scratch`
+
+// The two internal streams overlapped launches run on (one per workspace slot), per device, created on first use and kept
+// until the process ends; every scene on the device uses them.  They have different priorities: the runtime keeps separate
+// hardware-queue pools per priority, so the two can never be mapped onto one hardware queue (GPU_MAX_HW_QUEUES is 4 per
+// process and streams share queues; two equal-priority streams that land on the same queue would run their kernels one after
+// the other — observed).  They are shared rather than per scene because every priority stream may bring a hardware queue of
+// its own: with ten of them (five scenes) the device's queues were oversubscribed and a chain of one-frame launches — kernel on
+// a slot stream, fold on the caller's stream, each waiting for the other's event — stopped making progress (tools/soak.py
+// found it).  Sharing only orders different scenes' overlapped launches among themselves.  `device` must be current.
+static std::mutex g_streams_mutex;
+static hipStream_t g_slot_stream[64][2];
+static int slot_streams(int device, hipStream_t out[2]) {
+    if (device < 0 || device >= 64) return set_error(RT_ERR_INVALID_ARG, "device %d: the stream table holds 64 devices", device);
+    std::lock_guard<std::mutex> lock(g_streams_mutex);
+    if (!g_slot_stream[device][0]) {
+        int prio_least = 0, prio_greatest = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        hipStream_t a = nullptr, b = nullptr;
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&a, hipStreamNonBlocking, prio_least);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&b, hipStreamNonBlocking, prio_greatest);
+        if (e != hipSuccess) {
+            if (a) (void)hipStreamDestroy(a);
+            return set_error(RT_ERR_HIP, "creating the internal streams on device %d: %s", device, hipGetErrorString(e));
+        }
+        g_slot_stream[device][0] = a, g_slot_stream[device][1] = b;
+    }
+    out[0] = g_slot_stream[device][0], out[1] = g_slot_stream[device][1];
+    return RT_OK;
+}
 
 // `device` must be current.
 static int scratch_address(int device, unsigned char** out) {

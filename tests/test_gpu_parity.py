@@ -285,6 +285,28 @@ def test_entry_bvh_walk_spills_its_stack_exactly(hdr_pair):
     assert ex["internal_nodes"] < ost["internal_nodes"] // 4  # the walk that ran visits a fraction of the deck
 
 
+@pytest.mark.timeout(120)
+def test_many_live_scenes_do_not_stall_overlapped_launches(scene_small, hdr_pair):
+    """Every scene used to bring two priority streams of its own; with five scenes alive the device's hardware queues were
+    oversubscribed and a chain of one-frame launches (kernel on an internal stream, fold on the caller's, each waiting for the
+    other's event) never finished (found by tools/soak.py).  The two internal streams are now per device.  Eight scenes alive, 33
+    overlapped one-frame launches on each in turn through the host-buffer entry point: all return, results equal one call."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    live = [rt.Scene(tris, nodes, hdr, cache, entry_bvh=k % 2) for k in range(8)]
+    eye, cam = rt.camera(214.0, -7.5, 4.76)
+    d = rt.make_desc(658, 9, mode=4, eye=eye, camera_rotate=cam, accumulate=rt.RT_ACCUM_SUM)
+    ref = None
+    for sc in live:
+        sc.set_tuning(launch_frames=1, unit_frames=1, shade_lanes=1, wait_budget=100)
+        img = sc.render(d, 4655, 33)
+        sc.set_tuning(launch_frames=64, overlap_frames=1)
+        one = sc.render(d, 4655, 33)
+        assert np.array_equal(_bits(img), _bits(one))
+        ref = img if ref is None else ref
+        assert np.array_equal(_bits(img), _bits(ref))
+
+
 def test_mode5_rejects_more_bounces_than_the_sobol_table_holds(scene_small, hdr_pair):
     """f5:339 holds 8 Sobol dimensions = 4 bounces (f5:883, 949); a larger max_bounce would index past the table."""
     tris, nodes = scene_small

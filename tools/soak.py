@@ -7,6 +7,8 @@ import ray_tracing_amd as rt
 from ray_tracing_amd import scenes
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # replay: render only this launch (the random sequence is consumed as usual)
+verbose = len(sys.argv) > 2  # print every launch's parameters before it starts (to find one that does not return)
 rng = np.random.RandomState(12345)
 hdr, cache = scenes.hdr_and_cache()
 pool = [scenes.small_scene(), scenes.chap5_scene(), scenes.chap4_scene(), scenes.synthetic_scene(9, 10),
@@ -22,9 +24,19 @@ while time.time() - t0 < budget:
                   shade_lanes=rng.choice([1, 16, 48, 64]), leaf_lanes=rng.choice([1, 8, 64]),
                   wait_budget=rng.choice([1, 100, 4000, 10**8]), overlap_frames=rng.choice([1, 8, 1025]),
                   no_cull=rng.choice([0, 0, 1]), no_entry_bvh=rng.choice([0, 0, 1]))
-    eye, cam = rt.camera(float(rng.uniform(0, 360)), float(rng.uniform(-89, 89)), float(rng.uniform(0.05, 8)))
+    cam_args = (float(rng.uniform(0, 360)), float(rng.uniform(-89, 89)), float(rng.uniform(0.05, 8)))
+    eye, cam = rt.camera(*cam_args)
     d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam, accumulate=int(rng.randint(2)))
-    img = sc.render(d, int(rng.randint(0, 5000)), F)
+    fb = int(rng.randint(0, 5000))
+    if verbose:
+        tn = sc.tuning()
+        print(f"launch {k}: scene {objs.index(sc)} {W}x{H} F={F} fb={fb} mode={mode} acc={d.accumulate} camera={cam_args!r} tuning={[getattr(tn, f) for f, _ in tn._fields_]}", flush=True)
+    if only >= 0 and k != only:
+        k += 1
+        if k > only:
+            break
+        continue
+    img = sc.render(d, fb, F)
     assert img.shape == (H, W, 3)
     k += 1; paths += W * H * F
     if k % 50 == 0:
