@@ -307,6 +307,40 @@ def test_many_live_scenes_do_not_stall_overlapped_launches(scene_small, hdr_pair
         assert np.array_equal(_bits(img), _bits(ref))
 
 
+@pytest.mark.timeout(120)
+def test_two_threads_render_two_scenes_at_once(scene_small, scene_chap4, hdr_pair):
+    """Scenes are independent: two host threads, each with its own scene, issue overlapped one-frame launches
+    and batched launches at the same time — on the device's two shared internal streams — and get the images they get alone."""
+    import threading
+    hdr, cache = hdr_pair
+    jobs = []
+    for (tris, nodes), mode, eye_args in ((scene_small, 5, (20.0, 15.0, 3.0)), (scene_chap4, 4, (0.0, 0.0, 4.0))):
+        sc = rt.Scene(tris, nodes, hdr, cache)
+        eye, cam = rt.camera(*eye_args)
+        d = rt.make_desc(160, 90, mode=mode, eye=eye, camera_rotate=cam)
+        alone = sc.render(d, 0, 24)
+        jobs.append((sc, d, alone))
+    out, err = [None, None], []
+
+    def work(i):
+        try:
+            sc, d, _ = jobs[i]
+            for rep in range(6):
+                sc.set_tuning(launch_frames=1 if (rep + i) % 2 == 0 else 32)
+                out[i] = sc.render(d, 0, 24)
+        except Exception as ex:  # noqa: BLE001
+            err.append(ex)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for i in range(2):
+        assert np.array_equal(_bits(out[i]), _bits(jobs[i][2]))
+
+
 def test_mode5_rejects_more_bounces_than_the_sobol_table_holds(scene_small, hdr_pair):
     """f5:339 holds 8 Sobol dimensions = 4 bounces (f5:883, 949); a larger max_bounce would index past the table."""
     tris, nodes = scene_small
