@@ -14,6 +14,13 @@ hdr, cache = scenes.hdr_and_cache()
 pool = [scenes.small_scene(), scenes.chap5_scene(), scenes.chap4_scene(), scenes.synthetic_scene(9, 10),
         (np.zeros((0, 36), np.float32), np.zeros((1, 12), np.float32))]
 objs = [rt.Scene(t, n, hdr, cache) for t, n in pool] + [rt.Scene(t, n, hdr, cache, entry_bvh=1) for t, n in pool[:4]]
+use_torch = True
+try:
+    import torch
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+except Exception:  # noqa: BLE001
+    use_torch = False
+keep = []
 t0 = time.time(); k = 0; paths = 0
 while time.time() - t0 < budget:
     sc = objs[rng.randint(len(objs))]
@@ -36,9 +43,32 @@ while time.time() - t0 < budget:
         if k > only:
             break
         continue
-    img = sc.render(d, fb, F)
-    assert img.shape == (H, W, 3)
+    how = int(rng.randint(5)) if use_torch else 0
+    if how <= 1:
+        img = sc.render(d, fb, F)                       # host buffer, the library's NULL stream
+        assert img.shape == (H, W, 3)
+    else:
+        st = streams[int(rng.randint(len(streams)))]
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        with torch.cuda.stream(st):
+            if how == 2 or W * H * 12 > (40 << 20):
+                sc.render_device(d, fb, F, acc.data_ptr(), st.cuda_stream)
+            elif how == 3:
+                try:
+                    sc.render_device_noalloc(d, fb, min(F, 3), acc.data_ptr(), st.cuda_stream)
+                except rt.RtError:
+                    pass                                    # does not fit the static scratch array: a clean refusal
+            else:
+                sc.primary_hits(d)
+        if rng.randint(4) == 0:
+            torch.cuda.synchronize()
+        keep.append(acc)
+        if len(keep) > 8:
+            torch.cuda.synchronize()
+            keep.clear()
     k += 1; paths += W * H * F
     if k % 50 == 0:
         print(f"{k} launches, {paths / 1e6:.0f} Mpaths, {time.time() - t0:.0f} s", flush=True)
+if use_torch:
+    torch.cuda.synchronize()
 print(f"soak ok: {k} launches, {paths / 1e6:.0f} Mpaths in {time.time() - t0:.0f} s")
