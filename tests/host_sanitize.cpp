@@ -90,6 +90,39 @@ int main(int argc, char** argv) {
             }
             rt_free(nodes);
         }
+    // a mesh large enough for the builders' all-threads path (exact_sort.h, chunked sweeps): 2 x 300 x 240 lattice triangles,
+    // centroid coordinates tie by the thousand
+    {
+        const std::string p = tmp + "/rt_sanitize_lattice.obj";
+        FILE* f = fopen(p.c_str(), "w");
+        CHECK(f != nullptr);
+        const int nx = 300, nz = 240;
+        for (int i = 0; i <= nx; ++i)
+            for (int j = 0; j <= nz; ++j) fprintf(f, "v %d %d %d\n", i, (i * 7 + j * 3) % 5, j);
+        for (int i = 0; i < nx; ++i)
+            for (int j = 0; j < nz; ++j) {
+                const int a = i * (nz + 1) + j + 1, b = a + nz + 1;
+                fprintf(f, "f %d %d %d\nf %d %d %d\n", a, b, b + 1, a, b + 1, a + 1);
+            }
+        fclose(f);
+        rt_mesh* big = nullptr;
+        CHECK(rt_mesh_create(&big) == RT_OK);
+        float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        CHECK(rt_mesh_read_obj(big, p.c_str(), &m, I, 0) == RT_OK && rt_mesh_count(big) == 2 * nx * nz);
+        remove(p.c_str());
+        for (int sah = 0; sah < 2; ++sah) {
+            float* bn = nullptr;
+            int bnN = 0;
+            CHECK(rt_bvh_build(big, 8, sah, &bn, &bnN) == RT_OK && bnN > 2 * nx * nz / 8);
+            if (sah) {
+                rta::ScenePrep prep;
+                CHECK(rta::prepare_scene(rt_mesh_data(big), rt_mesh_count(big), bn, bnN, nullptr, nullptr, 0, 0, 1, &prep) == RT_OK);
+                CHECK(prep.has_entry && prep.rec2.size() % 32 == 0 && prep.stack2 > 0);
+            }
+            rt_free(bn);
+        }
+        rt_mesh_destroy(big);
+    }
     // empty mesh
     rt_mesh* empty = nullptr;
     CHECK(rt_mesh_create(&empty) == RT_OK);
