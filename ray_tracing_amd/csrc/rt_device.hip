@@ -1344,6 +1344,7 @@ static int check_render_args(const rt_scene* s, const rt_render_desc* d, int fra
     if (rc != RT_OK) return rc;
     if (!accum_dev) return set_error(RT_ERR_INVALID_ARG, "rt_render: accum is NULL");
     if (frame_begin < 0 || frame_count < 0) return set_error(RT_ERR_INVALID_ARG, "rt_render: negative frame range");
+    if (frame_count > 0x7fffffff - frame_begin) return set_error(RT_ERR_INVALID_ARG, "rt_render: frames %d + %d run past 2^31 - 1", frame_begin, frame_count);
     if (d->mode != RT_MODE_CHAP3 && d->mode != RT_MODE_CHAP4 && d->mode != RT_MODE_CHAP5)
         return set_error(RT_ERR_INVALID_ARG, "rt_render: unknown mode %d", d->mode);
     if (d->accumulate != RT_ACCUM_RUNNING_MEAN && d->accumulate != RT_ACCUM_SUM)
@@ -1709,6 +1710,7 @@ int rt_render_multi(rt_scene* const* scenes, int n_scenes, const rt_render_desc*
     // launches are asynchronous), then the buffers are added into sum_host in scene order (deterministic fp32 order).
     if (!scenes || n_scenes <= 0 || !d || !sum_host) return set_error(RT_ERR_INVALID_ARG, "rt_render_multi: bad arguments");
     if (frames_each < 0 || frame_begin < 0) return set_error(RT_ERR_INVALID_ARG, "rt_render_multi: negative frame range");
+    if ((long long)frames_each * n_scenes > 0x7fffffffll - frame_begin) return set_error(RT_ERR_INVALID_ARG, "rt_render_multi: the frame range runs past 2^31 - 1");
     rt_render_desc ds = *d;
     ds.accumulate = RT_ACCUM_SUM;
     const size_t n = (size_t)(d->width > 0 ? d->width : 0) * (size_t)(d->height > 0 ? d->height : 0) * 3;

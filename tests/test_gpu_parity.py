@@ -341,6 +341,19 @@ def test_two_threads_render_two_scenes_at_once(scene_small, scene_chap4, hdr_pai
         assert np.array_equal(_bits(out[i]), _bits(jobs[i][2]))
 
 
+def test_frame_ranges_past_int_max_are_refused(scene_small, hdr_pair):
+    """frameCounter is an int at the ABI (an unsigned int in the reference, c5:705): a range that would run past 2^31 - 1 is an
+    error, not a wrapped counter; the last representable frames still render."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    d = rt.make_desc(16, 8, mode=5)
+    with pytest.raises(rt.RtError):
+        sc.render(d, 2**31 - 10, 11)
+    img = sc.render(d, 2**31 - 10, 9)
+    assert np.isfinite(img).all()
+
+
 def test_mode5_rejects_more_bounces_than_the_sobol_table_holds(scene_small, hdr_pair):
     """f5:339 holds 8 Sobol dimensions = 4 bounces (f5:883, 949); a larger max_bounce would index past the table."""
     tris, nodes = scene_small
