@@ -408,12 +408,16 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
 
     // lane state
     int op = OP_DONE;
-    int kind = K_PRIMARY;
     int pxy = 0;                    // the sample this lane works on: pixel (px | py << 16) ...
-    int fidx = 0;                   // ... and frame, counted from frame_begin
+    // ... its frame, counted from frame_begin (bits 0-9: a launch has at most 1024), the bounce the path is in (bits 10-29) and
+    // the kind of the ray in flight (bits 30-31) share one register: all three are shade-pass state
+    unsigned fbk = 0;
+#define FIDX_ ((int)(fbk & 1023u))
+#define BOUNCE_ ((int)((fbk >> 10) & 0xfffffu))
+#define KIND_ ((int)(fbk >> 30))
+#define SET_KIND_(k_) (fbk = (fbk & 0x3fffffffu) | ((unsigned)(k_) << 30))
     float cpu = 0.0f, cpv = 0.0f;   // Cranley-Patterson shift of that pixel (f5:367-383)
     unsigned seed = 0;
-    int bounce = 0;
     vec3 d = v3(0, 0, 1), invdir = v3(0);  // ray in flight
     // Its origin: kept in registers by the entry-BVH instantiations only.  The others read it back from the LDS ray table (s_ray)
     // where a pass needs it: three live registers fewer across the whole loop are worth 1-2 % on config 5 (measured), while the
@@ -471,8 +475,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             // `kind`), step by step; a step runs once for all lanes that need it ------------------------------------
             bool to_B = false, to_C = false, fin = false, emit = false;
             const bool h = (op == OP_H);
-            const bool isA = h && kind == K_PRIMARY, isD = h && kind == K_BOUNCE;
-            const bool isC = h && (kind == K_SHADOW || kind == K_NONE);
+            const bool isA = h && KIND_ == K_PRIMARY, isD = h && KIND_ == K_BOUNCE;
+            const bool isC = h && (KIND_ == K_SHADOW || KIND_ == K_NONE);
             const bool miss = best_tri < 0;
             const vec3 L = d;  // direction of the ray that came back
             vec3 S = v3(0);    // its origin (read back only where the hit record is finished); then the next ray's
@@ -480,7 +484,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             // f4:520, f3:396), the env-visibility ray when it was not occluded (f5:875-876)
             vec3 f_r = v3(0);
             float pdf_brdf = 0.0f;
-            const bool need_eval = isD || (h && kind == K_SHADOW && miss);
+            const bool need_eval = isD || (h && KIND_ == K_SHADOW && miss);
 #ifdef RT_SHADE_CYCLES
             scy_t = clock64(), scy[8]++;
 #endif
@@ -502,7 +506,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             }
             // step 2: environment radiance (and its pdf) along L for every ray that escaped (f5:945, 873-874, 906-907)
             const bool d_alive = isD && (MODE != RT_MODE_CHAP5 || !(pdf_brdf <= 0.0f));  // f5:901
-            const bool need_env = (isA && miss) || (h && kind == K_SHADOW && miss) || (d_alive && miss);
+            const bool need_env = (isA && miss) || (h && KIND_ == K_SHADOW && miss) || (d_alive && miss);
             vec3 color = v3(0);
             float pdf_light = 0.0f;
             SHADE_MARK(0);  // BRDF eval
@@ -529,7 +533,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (MODE == RT_MODE_CHAP5) {
                 // f5:879-880 (env-visibility ray escaped), f5:910-911 (BRDF ray escaped), f5:915 + 920 (BRDF ray hit): three
                 // disjoint sets of lanes, one shared quotient.  Each lane's numerator is built in its own line's order.
-                const bool c_miss = h && kind == K_SHADOW && miss, d_miss = d_alive && miss, d_hit = d_alive && !miss;
+                const bool c_miss = h && KIND_ == K_SHADOW && miss, d_miss = d_alive && miss, d_hit = d_alive && !miss;
                 if (isD && !d_alive) fin = true;  // f5:901
                 if (c_miss || d_miss || d_hit) {
                     const float NdotL = dot(N, L);
@@ -571,13 +575,13 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                             Lo += history * Le * f_r * cosine_i / pdf_uniform;  // f3:407
                         history *= f_r * cosine_i / pdf_uniform;
                     }
-                    bounce++;
+                    fbk += 1u << 10;  // bounce++
                 } else {
                     first_tri = best_tri;
-                    Lo = v3(0), history = v3(1), bounce = 0;
+                    Lo = v3(0), history = v3(1), fbk &= ~(0xfffffu << 10);  // bounce = 0
                 }
                 hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
-                if (bounce < P.max_bounce) to_B = true; else fin = true;
+                if (BOUNCE_ < P.max_bounce) to_B = true; else fin = true;
             }
             // ---- start of a bounce (f5:856-866 env sample; chapters 3/4: the hemisphere sample) ------------------
             SHADE_MARK(3);  // finish hit
@@ -590,13 +594,13 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     const float4 ce = sc.cdir[texel_index(r2, sc.hdrH) * sc.hdrW + texel_index(r1, sc.hdrW)];
                     const vec3 Lh = v3(ce.x, ce.y, ce.z);
                     if (dot(N, Lh) > 0.0f) {
-                        S = hitP, d = Lh, kind = K_SHADOW, emit = true;
+                        S = hitP, d = Lh, SET_KIND_(K_SHADOW), emit = true;
                     } else {
-                        kind = K_NONE, to_C = true;  // no visibility ray: straight to BRDF sampling
+                        SET_KIND_(K_NONE), to_C = true;  // no visibility ray: straight to BRDF sampling
                     }
                 } else {
                     const vec3 Lu = toNormalHemisphere(SampleHemisphereRand(seed), N);
-                    S = hitP, d = Lu, kind = K_BOUNCE, emit = true;
+                    S = hitP, d = Lu, SET_KIND_(K_BOUNCE), emit = true;
                 }
             }
             // ---- BRDF importance sampling (f5:883-895): after the env-visibility ray, or at once when it was skipped ---
@@ -604,7 +608,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (STATS) { const int c_ = __popcll(__ballot(isC || to_C)); if (lane == 0) sg[4] += c_; }
             if (MODE == RT_MODE_CHAP5 && (isC || to_C)) {
                 const MatPre pre = load_mat_pre(sc, surf_tri);
-                const float2 sb = P.sobol[fidx * 4 + bounce];  // sobolVec2(frameCounter + 1, bounce): depends on (frame, bounce) only
+                const float2 sb = P.sobol[FIDX_ * 4 + BOUNCE_];  // sobolVec2(frameCounter + 1, bounce): depends on (frame, bounce) only
                 const float xi_1 = cp_rotate(sb.x, cpu);
                 const float xi_2 = cp_rotate(sb.y, cpv);
                 const float xi_3 = rand01(seed);
@@ -612,7 +616,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 if (dot(N, Ls) <= 0.0f) {
                     fin = true;
                 } else {
-                    S = hitP, d = Ls, kind = K_BOUNCE, emit = true;
+                    S = hitP, d = Ls, SET_KIND_(K_BOUNCE), emit = true;
                 }
             }
             // ---- end of a sample: Le + Li (f5:950) goes to the launch's sample buffer ----------------------------------
@@ -624,7 +628,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     const float* T = sc.tris + (size_t)first_tri * 36 + 18;
                     sample = v3(T[0], T[1], T[2]) + Lo;
                 }
-                float* o = P.samples + ((size_t)fidx * n_pixels + (size_t)(pxy >> 16) * P.width + (pxy & 0xffff)) * 3;
+                float* o = P.samples + ((size_t)FIDX_ * n_pixels + (size_t)(pxy >> 16) * P.width + (pxy & 0xffff)) * 3;
                 o[0] = sample.x, o[1] = sample.y, o[2] = sample.z;
                 if (STATS) paths++;
                 need_new = true;
@@ -667,7 +671,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     const int it = next_item + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(asking >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)asking, 0u));
                     if (it < unit_items) {
                         const int ix = unit_tx0 + (it & 7), iy = unit_ty0 + ((it >> 3) & 7);
-                        pxy = ix | (iy << 16), fidx = unit_f0 + (it >> 6);
+                        pxy = ix | (iy << 16), fbk = (fbk & ~1023u) | (unsigned)(unit_f0 + (it >> 6));
                         got = ix < P.width && iy < P.height;
                     }
                 }
@@ -681,7 +685,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     const float pixx = -1.0f + 2.0f * ((float)(pxy & 0xffff) + 0.5f) / (float)P.width;
                     const float pixy = -1.0f + 2.0f * ((float)(pxy >> 16) + 0.5f) / (float)P.height;
                     if (MODE == RT_MODE_CHAP5) cp_shift(pixx, pixy, P.width, P.height, &cpu, &cpv);
-                    seed = pixel_seed(pixx, pixy, P.width, P.height, (unsigned)(P.frame_begin + fidx));
+                    seed = pixel_seed(pixx, pixy, P.width, P.height, (unsigned)(P.frame_begin + FIDX_));
                     const float aax = (rand01(seed) - 0.5f) / (float)P.width;
                     const float aay = (rand01(seed) - 0.5f) / (float)P.height;
                     const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
@@ -690,7 +694,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     dir.x = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
                     dir.y = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
                     dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
-                    S = v3(P.eye[0], P.eye[1], P.eye[2]), d = normalize(dir), kind = K_PRIMARY, emit = true;
+                    S = v3(P.eye[0], P.eye[1], P.eye[2]), d = normalize(dir), SET_KIND_(K_PRIMARY), emit = true;
                 }
             }
             // ---- hitBVH prologue (f5:260-268) --------------------------------------------------------------------
@@ -898,7 +902,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                         best = t;
                         best_tri = (int)(unsigned)key;
                         // an env-visibility ray only needs isHit (f5:869); statistics builds count the full walk
-                        if (CULL && kind == K_SHADOW) done = true;
+                        if (CULL && KIND_ == K_SHADOW) done = true;
                     }
                 }
                 ti += serve;
@@ -921,7 +925,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
         }
         // ---- a walk ended: the next phase of the same ray, or the ray is done ----------------------------------------------
         if (ENTRY && op == OP_END) {
-            if (ENTRY && phase == 0 && best_tri >= 0 && !(tie && kind != K_SHADOW)) {
+            if (ENTRY && phase == 0 && best_tri >= 0 && !(tie && KIND_ != K_SHADOW)) {
                 // the entry BVH's closest (env-visibility rays: first) acceptable hit W: climb from its reference leaf
                 const int w = sc.map2[best_tri];
                 const unsigned lx = sc.leafx[w];
@@ -990,6 +994,10 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             for (int k = 0; k < 8; ++k) atomicAdd(&P.stats[18 + k], (unsigned long long)sg[k]);
     }
 }
+#undef FIDX_
+#undef BOUNCE_
+#undef KIND_
+#undef SET_KIND_
 
 // sobolVec2(i, b) (f5:362-365) for the launch's frames (i = frameCounter + 1, f5:883) and the four bounces of chapter 5.
 __global__ void __launch_bounds__(128) sobol_table_kernel(float2* out, int frame_begin, int frame_count) {
