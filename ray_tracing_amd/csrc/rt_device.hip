@@ -441,7 +441,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     // Phases 1 / 2 alone decide results; the entry BVH only decides how much of the reference tree has to be walked.
     int phase = 2;
     bool tie = false;               // phase 0: another triangle has exactly the closest distance
-    int cur = 0, sp = 0, best_tri = -1, ti = 0;        // ti: next triangle of the leaf in `cur`
+    int cur = 0, sp = 0, best_tri = -1;  // cur: record of the internal node to visit, or (< 0) the leaf being scanned — a leaf entry
+                                         // shrinks as its triangles are served: its first triangle is the next one to test
     float best = INF_;
     float leaf_best = INF_;         // STATS only
     vec3 hitP = v3(0), N = v3(0), V = v3(0);  // current surface point: hit.hitPoint, hit.normal, -hit.viewDir
@@ -717,7 +718,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 } else if (cur >= 0) {
                     op = OP_INT;
                 } else {
-                    op = OP_LEAF, ti = cur & 0x00ffffff, leaf_best = INF_;
+                    op = OP_LEAF, leaf_best = INF_;
                     if (STATS) st.leaves++;
                 }
             }
@@ -832,7 +833,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     cur = wstack_pop<SPILL>(stk_lds, stk_spill, stk_stride, --sp);
                 }
                 if (!popped && cur < 0) {
-                    op = OP_LEAF, ti = cur & 0x00ffffff, leaf_best = INF_;
+                    op = OP_LEAF, leaf_best = INF_;
                     if (STATS) st.leaves++;
                 }
             }
@@ -845,8 +846,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             // sequential scan with strict < keeps — and the owner then applies `t < best` (strict: an earlier leaf keeps
             // a tie, f5:278).  Triangles are consumed in index order, leaves in stack order: per ray nothing changes.
             const bool leaf = (op == OP_LEAF);
-            const int end = (cur & 0x00ffffff) + ((cur >> 24) & 0x7f) + 1;
-            const int rem = leaf ? (end - ti) : 0;
+            const int ti = cur & 0x00ffffff;
+            const int rem = leaf ? ((cur >> 24) & 0x7f) + 1 : 0;
             const int incl = wave_inclusive_sum(rem);
             const int start = incl - rem;
             int serve = 64 - start;
@@ -905,8 +906,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                         if (CULL && KIND_ == K_SHADOW) done = true;
                     }
                 }
-                ti += serve;
-                if (!done && ti >= end) {
+                if (!done && serve < rem) {
+                    cur = (int)(0x80000000u | ((unsigned)(rem - serve - 1) << 24) | (unsigned)(ti + serve));  // the rest of this leaf
+                } else if (!done) {
                     if (sp == 0) {
                         done = true;
                     } else {
@@ -914,7 +916,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                         if (cur >= 0) {
                             op = OP_INT;
                         } else {
-                            ti = cur & 0x00ffffff, leaf_best = INF_;
+                            leaf_best = INF_;
                             if (STATS) st.leaves++;
                         }
                     }
@@ -946,7 +948,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 if (cur >= 0) {
                     op = OP_INT;
                 } else {
-                    op = OP_LEAF, ti = cur & 0x00ffffff, leaf_best = INF_;
+                    op = OP_LEAF, leaf_best = INF_;
                     if (STATS) st.leaves++;
                 }
             } else {
