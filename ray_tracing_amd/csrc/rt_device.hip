@@ -382,7 +382,7 @@ __device__ __forceinline__ int wave_inclusive_sum(int x) {
 template <int MODE, bool STATS, bool SPILL, bool ENTRY>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU))) render_kernel(const RenderParams P) {
     __shared__ int s_stack[kLdsDepth * kWave];        // per-lane traversal stacks, [depth][lane]
-    __shared__ float4 s_ray[2 * kWave];                // per-lane ray in flight: (S.xyz, d.x) (d.yz, -, -)
+    __shared__ float4 s_ray[2 * kWave];                // per lane: the ray in flight (S.xyz, d.x) (d.yz, phase, primary-hit triangle of the path)
     __shared__ int s_item[kWave];                      // cooperative leaf pass: item -> (triangle << 6 | owner lane)
     __shared__ unsigned long long s_key[kWave];        // per owner: min over its items of (t bits << 32 | triangle)
     __shared__ float s_t[kWave];                       // STATS builds: per item hit distance (INF = miss)
@@ -447,7 +447,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     float leaf_best = INF_;         // STATS only
     vec3 hitP = v3(0), N = v3(0), V = v3(0);  // current surface point: hit.hitPoint, hit.normal, -hit.viewDir
     int surf_tri = -1;              // triangle of the current surface point (material source)
-    int first_tri = -1;             // triangle of the primary hit (Le), -1 = primary miss
+    // (the triangle of the path's primary hit — Le at the end of the sample, -1 = primary miss — is written and read once per
+    // sample: it lives in the spare word of the lane's LDS ray-table entry, s_ray[2 * lane + 1].w, not in a register)
     vec3 Lo = v3(0), history = v3(1);
 
 #ifdef RT_OP_CYCLES
@@ -527,7 +528,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             SHADE_MARK(1);  // env lookup
             // step 3: what each kind of ray adds
             if (isA && miss) {
-                Lo = color, first_tri = -1, fin = true;
+                Lo = color, s_ray[2 * lane + 1].w = __int_as_float(-1), fin = true;
             }
             const float cosine_i = fmax_(0.0f, dot(N, L));  // chapters 3/4
             const float pdf_uniform = 1.0f / (2.0f * PI_);
@@ -578,7 +579,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                     }
                     fbk += 1u << 10;  // bounce++
                 } else {
-                    first_tri = best_tri;
+                    s_ray[2 * lane + 1].w = __int_as_float(best_tri);
                     Lo = v3(0), history = v3(1), fbk &= ~(0xfffffu << 10);  // bounce = 0
                 }
                 hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
@@ -625,6 +626,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (STATS) { const int c_ = __popcll(__ballot(fin)); if (lane == 0) sg[5] += c_; }
             if (fin) {
                 vec3 sample = Lo;
+                const int first_tri = __float_as_int(s_ray[2 * lane + 1].w);
                 if (first_tri >= 0) {
                     const float* T = sc.tris + (size_t)first_tri * 36 + 18;
                     sample = v3(T[0], T[1], T[2]) + Lo;
@@ -712,7 +714,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 cur = (ENTRY && phase == 0) ? sc.root_entry2 : sc.root_entry;
                 if (ENTRY) S_reg = S;
                 s_ray[2 * lane] = make_float4(S.x, S.y, S.z, d.x);  // for the cooperative leaf pass
-                s_ray[2 * lane + 1] = make_float4(d.y, d.z, __int_as_float(phase), 0.0f);
+                s_ray[2 * lane + 1].x = d.y, s_ray[2 * lane + 1].y = d.z, s_ray[2 * lane + 1].z = __int_as_float(phase);  // (.w: the primary hit)
                 if (!sc.has_root) {
                     op = OP_H;
                 } else if (cur >= 0) {
