@@ -418,11 +418,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
 #define SET_KIND_(k_) (fbk = (fbk & 0x3fffffffu) | ((unsigned)(k_) << 30))
     float cpu = 0.0f, cpv = 0.0f;   // Cranley-Patterson shift of that pixel (f5:367-383)
     unsigned seed = 0;
-    vec3 d = v3(0, 0, 1), invdir = v3(0);  // ray in flight
-    // Its origin: kept in registers by the entry-BVH instantiations only.  The others read it back from the LDS ray table (s_ray)
-    // where a pass needs it: three live registers fewer across the whole loop are worth 1-2 % on config 5 (measured), while the
-    // entry-BVH kernels, whose internal-node pass is the hot one, lose 2 % to the extra LDS read.
-    vec3 S_reg = v3(0);
+    vec3 d = v3(0, 0, 1), invdir = v3(0);  // ray in flight.  Its origin is read back from the LDS ray table (s_ray) where a pass
+                                           // needs it: three live registers fewer across the whole loop (1-2 % on config 5)
     bool slow = false;              // this ray needs the NaN-exact box test
     // statistics builds walk exactly the reference's nodes (algorithmic counts) unless asked for the executed walk
     const bool CULL = !STATS || P.stats_executed != 0;
@@ -560,9 +557,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             SHADE_MARK(2);  // contributions
             if (STATS) { const int c_ = __popcll(__ballot((isA || d_alive) && !miss)); if (lane == 0) sg[2] += c_; }
             if ((isA || d_alive) && !miss) {
-                if (ENTRY) {
-                    S = S_reg;
-                } else {
+                {
                     const float4 sr = s_ray[2 * lane];
                     S = v3(sr.x, sr.y, sr.z);
                 }
@@ -712,7 +707,6 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 phase = (ENTRY && ceps < __builtin_inff()) ? 0 : 2;
                 tie = false;
                 cur = (ENTRY && phase == 0) ? sc.root_entry2 : sc.root_entry;
-                if (ENTRY) S_reg = S;
                 s_ray[2 * lane] = make_float4(S.x, S.y, S.z, d.x);  // for the cooperative leaf pass
                 s_ray[2 * lane + 1].x = d.y, s_ray[2 * lane + 1].y = d.z, s_ray[2 * lane + 1].z = __int_as_float(phase);  // (.w: the primary hit)
                 if (!sc.has_root) {
@@ -742,11 +736,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 const vec3 rAA = v3(q1.z, q1.w, q2.x), rBB = v3(q2.y, q2.z, q2.w);
                 // a child whose inflated box starts beyond the closest hit so far cannot change the result: skip it
                 // (ceps = +inf for rays that must not be culled: then c1 = c2 = -inf)
-                vec3 S = S_reg;
-                if (!ENTRY) {
-                    const float4 sr = s_ray[2 * lane];  // (written by this lane's own prologue; same wave: no barrier needed)
-                    S = v3(sr.x, sr.y, sr.z);
-                }
+                const float4 sr = s_ray[2 * lane];  // (written by this lane's own prologue; same wave: no barrier needed)
+                const vec3 S = v3(sr.x, sr.y, sr.z);
                 float c1, c2, e1, e2;
                 float d1 = hitAABB_cull(S, invdir, lAA, lBB, ceps, q3.z, &c1, ENTRY ? &e1 : nullptr);
                 float d2 = hitAABB_cull(S, invdir, rAA, rBB, ceps, q3.w, &c2, ENTRY ? &e2 : nullptr);
