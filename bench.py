@@ -51,7 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=32, help="frames (samples per pixel) per step per GPU")
+    ap.add_argument("--spp", type=int, default=64, help="frames (samples per pixel) per step per GPU (default: one launch, rt_tuning.launch_frames)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--mode", type=int, default=5, choices=[3, 4, 5])
@@ -315,8 +315,9 @@ def main():
             rays_per_path = ex["rays"] / max(ex["paths"], 1)
             I, Lf, T, Hh = (ex[k] / rays for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"))
             rI, rLf, rT, rH = (rf[k] / max(rf["rays"], 1) for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"))
-            paths_per_launch = float(W) * H * min(spp, 32)  # rt_tuning.launch_frames = 32
-            launches_per_step = max(1, (spp + 31) // 32)
+            lf = max(1, int(renderer.scene.tuning().launch_frames))  # frames per kernel launch
+            paths_per_launch = float(W) * H * min(spp, lf)
+            launches_per_step = max(1, (spp + lf - 1) // lf)
             # §8d flops: 50 per internal node + 90 per triangle test + 40 per closest-hit improvement, + 400 per shaded bounce;
             # every bounce emits at most one env-visibility and one BRDF ray, so bounces >= (rays - paths) / 2 (a lower bound)
             bounces_per_path = max(rays_per_path - 1.0, 0.0) / 2.0

@@ -195,7 +195,7 @@ int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_beg
 /* Scheduling knobs of the path loop, per scene (they change how the work is cut, never the image: tested).  Fields <= 0
  * select the default; rt_scene_set_tuning(s, NULL) restores all defaults.  No counterpart in the reference. */
 typedef struct rt_tuning {
-    int32_t launch_frames;     /* frames per kernel launch (sample buffer = W*H*launch_frames*12 B); default 32, max 1024 */
+    int32_t launch_frames;     /* frames per kernel launch (sample buffer = W*H*launch_frames*12 B); default 64, max 1024 */
     int32_t unit_frames;       /* frames per work unit (one 8x8 tile x unit_frames samples); default 2 */
     int32_t leaf_lanes;        /* lanes holding a leaf that trigger a cooperative leaf pass; default 8 */
     int32_t shade_lanes;       /* lanes waiting for the shade pass that trigger it; default 48 */
