@@ -438,6 +438,17 @@ def test_scene_cache_round_trip_and_rejections(tmp_path):
     open(path, "wb").write(raw[:-7])
     with pytest.raises(rt.RtError):  # truncated
         rt.scene_cache_load(path, key)
+    open(path, "wb").write(b"RTAMDSC1" + raw[8:])
+    with pytest.raises(rt.RtError):  # a format-1 file (byte-serial payload hash): refused, so cached_build rebuilds it
+        rt.scene_cache_load(path, key)
+    big = np.tile(np.ascontiguousarray(tris, np.float32), (120, 1))  # > one 4 MiB hash block: the block-wise hash covers every block
+    rt.scene_cache_save(path, key, big, nodes)
+    raw2 = bytearray(open(path, "rb").read())
+    assert len(raw2) > 48 + (5 << 20)
+    raw2[48 + (4 << 20) + 12345] ^= 1
+    open(path, "wb").write(bytes(raw2))
+    with pytest.raises(rt.RtError):  # one flipped bit in the second block
+        rt.scene_cache_load(path, key)
     # cached_build: builds once, then loads
     calls = []
 
