@@ -156,6 +156,10 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
     std::vector<int> order;                        // internal nodes in record order
     int max_depth = 0;
     const bool has_root = nN >= 2;
+    // per triangle: how many reachable leaves hold it (saturating at 2).  The reference only ever tests triangles of leaves it
+    // reaches (f5:243-256), so a triangle of no leaf can never be hit, and one held by two leaves has no single "its leaf"
+    std::vector<unsigned char> cover(nT > 0 ? nT : 0, 0);
+    bool leaves_overlap = false;
     if (has_root) {
         std::vector<char> seen(nN, 0);
         std::vector<std::pair<int, int>> stack;  // node, depth
@@ -176,6 +180,9 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
                 if (index < 0 || (long long)index + n > nT)
                     return set_error(RT_ERR_BAD_BVH, "rt_scene_create: leaf %d range [%d,%d) outside the %d triangles", id, index, index + n, nT);
                 entry[id] = pack_leaf(index, n);
+                for (int i = index; i < index + n; ++i) {
+                    if (cover[i]) leaves_overlap = true; else cover[i] = 1;
+                }
             } else {
                 if (l <= 0 || r <= 0)
                     return set_error(RT_ERR_BAD_BVH, "rt_scene_create: internal node %d lacks a child (left=%d right=%d)", id, l, r);
@@ -330,7 +337,8 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
     int root_entry2 = 0, depth2 = 0, stack2 = 0;  // stack2: stack entries a walk of the 4-wide entry BVH can hold
     double cost_ref = 0.0, cost_entry = 0.0;
     bool has_entry = false;
-    if (cull_eps < __builtin_inff() && !order.empty() && entry_mode >= 0 && (nT >= 1024 || entry_mode > 0)) {
+    // (not for a BVH whose leaves share triangles: the climb starts from THE leaf of the entry walk's hit)
+    if (cull_eps < __builtin_inff() && !order.empty() && entry_mode >= 0 && (nT >= 1024 || entry_mode > 0) && !leaves_overlap) {
         auto area = [](const float* lo, const float* hi) {
             const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
             return (x < 0 || y < 0 || z < 0) ? 0.0 : 2.0 * (x * y + x * z + y * z);
@@ -344,7 +352,7 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
             std::vector<char> use(nT, 0);
 #pragma omp parallel for schedule(static)
             for (int i = 0; i < nT; ++i) {
-                if (tri_margin[i] < 0.0f) continue;  // can never be hit
+                if (tri_margin[i] < 0.0f || !cover[i]) continue;  // can never be hit: not acceptable, or in no leaf the reference reaches
                 use[i] = 1;
                 const float* q = &ttri[(size_t)i * 12];
                 for (int c = 0; c < 3; ++c) {
@@ -416,7 +424,7 @@ int prepare_scene(const float* tris, int nT, const float* nodes, int nN, const f
                     climb_eps = 4.0f * cull_eps;
 #pragma omp parallel for schedule(dynamic, 4096)
                     for (int i = 0; i < nT; ++i) {
-                        if (tri_margin[i] < 0.0f) continue;
+                        if (tri_margin[i] < 0.0f || !cover[i]) continue;
                         const float* q = &ttri[(size_t)i * 12];
                         double lo[3], hi[3];
                         for (int c = 0; c < 3; ++c) {

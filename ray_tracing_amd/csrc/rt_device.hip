@@ -1070,6 +1070,14 @@ static void remember_launch(const TimedLaunch& tl) {
     g_launches.push_back(tl);
 }
 static thread_local int g_device = -1;
+constexpr int kMaxDevices = 64;
+// Which caller stream the overlapped launches of a device currently serve (see rt_render_device).
+struct OverlapOwner {
+    hipStream_t owner = nullptr;
+    bool has_owner = false, disabled = false;
+};
+static std::mutex g_overlap_mutex;
+static OverlapOwner g_overlap[kMaxDevices];
 static int scratch_address(int device, unsigned char** out);
 static int slot_streams(int device, hipStream_t out[2]);
 
@@ -1314,7 +1322,9 @@ struct WorkSlot {
     float2* sobol = nullptr;       // kMaxLaunchFrames x 4 Sobol pairs
     float* samples = nullptr;      // launch_frames x W x H x RGB
     int* spill = nullptr;          // global part of the traversal stacks (deep trees only)
-    rt_scene::Slot* pipe = nullptr;  // non-NULL: run the path-loop kernel on pipe->stream, ordered by pipe's events
+    rt_scene::Slot* owner = nullptr;  // the scene's slot these buffers belong to (NULL: the static scratch): its fold_done event
+                                      // orders every reuse of the buffers, whichever stream the previous user ran on
+    bool own_stream = false;       // run the path-loop kernel on owner->stream (overlapped launches), else on the caller's stream
 };
 struct Workspace {
     WorkSlot slot[2];
@@ -1408,8 +1418,11 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         // launch — other slot — is still draining its last paths; the fold then waits for it on the caller's stream
         const WorkSlot& w = ws.slot[ws.next_slot ? ((*ws.next_slot)++ % (unsigned)ws.n_slots) : 0];
         P.queue = w.queue, P.samples = w.samples, P.sobol = w.sobol, P.spill = w.spill;
-        const hipStream_t rstream = w.pipe ? w.pipe->stream : stream;
-        if (w.pipe && w.pipe->fold_recorded) HIPCHK(hipStreamWaitEvent(rstream, w.pipe->fold_done, 0));  // its samples have been folded
+        const bool piped = w.owner && w.own_stream;
+        const hipStream_t rstream = piped ? w.owner->stream : stream;
+        // the slot's previous user — overlapped or not, on whatever stream — has folded its samples (a wait on an event
+        // recorded on the same stream costs nothing)
+        if (w.owner && w.owner->fold_recorded) HIPCHK(hipStreamWaitEvent(rstream, w.owner->fold_done, 0));
         HIPCHK(hipMemsetAsync(w.queue, 0, 8 * 16 * sizeof(unsigned), rstream));
         if (d->mode == RT_MODE_CHAP5)
             hipLaunchKernelGGL(sobol_table_kernel, dim3((P.frame_count * 4 + 127) / 128), dim3(128), 0, rstream, w.sobol, P.frame_begin, P.frame_count);
@@ -1447,24 +1460,24 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
             HIPCHK(hipEventRecord(tl.b, rstream));
             remember_launch(tl);
         }
-        if (w.pipe) {
-            HIPCHK(hipEventRecord(w.pipe->render_done, rstream));
-            HIPCHK(hipStreamWaitEvent(stream, w.pipe->render_done, 0));
+        if (piped) {
+            HIPCHK(hipEventRecord(w.owner->render_done, rstream));
+            HIPCHK(hipStreamWaitEvent(stream, w.owner->render_done, 0));
         }
         hipLaunchKernelGGL(fold_kernel, dim3(fold_blocks), dim3(256), 0, stream, P);
         HIPCHK(hipGetLastError());
-        if (w.pipe) {
-            HIPCHK(hipEventRecord(w.pipe->fold_done, stream));
-            w.pipe->fold_recorded = true;
+        if (w.owner) {
+            HIPCHK(hipEventRecord(w.owner->fold_done, stream));
+            w.owner->fold_recorded = true;
         }
     }
     return RT_OK;
 }
 
-// Before a slot's buffer is freed or reused outside the pipeline: everything that touches it has finished.
+// Before a slot's buffer is freed: everything that touches it has finished (the fold is the last user of a launch's
+// buffers and waits for its path-loop kernel).
 static void quiesce_slot(rt_scene::Slot& sl) {
-    if (!sl.fold_recorded) return;  // never used by an overlapped launch since the last time
-    (void)hipStreamSynchronize(sl.stream);
+    if (!sl.fold_recorded) return;  // never used since the last time
     (void)hipEventSynchronize(sl.fold_done);
     sl.fold_recorded = false;
 }
@@ -1485,7 +1498,6 @@ static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count
     pipelined = pipelined && launch_frames < s->tuning.overlap_frames;
     ws->n_slots = pipelined ? 2 : 1;
     ws->next_slot = pipelined ? &s->next_slot : nullptr;
-    if (!pipelined) quiesce_slot(s->slot[0]);
     for (int k = 0; k < ws->n_slots; ++k) {
         rt_scene::Slot& sl = s->slot[k];
         if (per_frame * launch_frames > sl.samples_bytes) {
@@ -1505,7 +1517,7 @@ static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count
         }
         ws->slot[k].queue = sl.d_queue, ws->slot[k].sobol = sl.d_sobol, ws->slot[k].samples = sl.d_samples;
         ws->slot[k].spill = spill ? sl.d_spill : nullptr;
-        ws->slot[k].pipe = pipelined ? &sl : nullptr;
+        ws->slot[k].owner = &sl, ws->slot[k].own_stream = pipelined;
     }
     ws->clk = s->d_clk;
     ws->spill_stride = spill ? (long long)threads : 0;
@@ -1526,9 +1538,15 @@ constexpr size_t kScratchBodyOff = 65536;                                // stac
 static_assert(kScratchSobolOff + (size_t)kMaxLaunchFrames * 4 * sizeof(float2) <= kScratchBodyOff, "scratch header layout");
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
-constexpr int kMaxDevices = 64;
 static std::mutex g_scratch_mutex;
 static unsigned char* g_scratch_ptr[kMaxDevices];  // per device: the address of ITS copy of `scratch`
+// In-use guard of the scratch array: the last rt_render_device_noalloc call on a device records g_scratch_done on its stream
+// after its last fold.  A later call on the SAME stream is ordered behind it by the stream; a call on another stream while
+// that event has not completed would race on the array and is refused.  The event is created with the address look-up
+// (rt_init / rt_scene_create), so the entry point itself creates nothing.
+static hipEvent_t g_scratch_done[kMaxDevices];
+static hipStream_t g_scratch_stream[kMaxDevices];
+static bool g_scratch_used[kMaxDevices];
 
 // The two internal streams overlapped launches run on (one per workspace slot), per device, created on first use and kept
 // until the process ends; every scene on the device uses them.  They have different priorities: the runtime keeps separate
@@ -1567,6 +1585,10 @@ static int scratch_address(int device, unsigned char** out) {
         void* p = nullptr;
         const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess || !p) return set_error(RT_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+        hipEvent_t ev = nullptr;
+        const hipError_t e2 = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e2 != hipSuccess) return set_error(RT_ERR_HIP, "creating the scratch guard event on device %d: %s", device, hipGetErrorString(e2));
+        g_scratch_done[device] = ev;
         g_scratch_ptr[device] = (unsigned char*)p;
     }
     *out = g_scratch_ptr[device];
@@ -1624,8 +1646,32 @@ int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int 
     if (rc != RT_OK) return rc;
     if (frame_count == 0) return RT_OK;
     GUARD_DEVICE(s);
+    // Overlapped launches put the path-loop kernel on one of the two internal (priority) streams and the fold on the caller's,
+    // each waiting for the other's event.  Measured on MI355X / ROCm 7.2 (tools/stream_probe*.py): driven from ONE caller
+    // stream that chain runs (8 live scenes, thousands of launches); as soon as overlapped launches come from a second and third
+    // caller stream — even one after the other, each finished before the next starts — an internal stream stops making
+    // progress, and a caller that brings priority streams competes for the same small per-priority hardware-queue pools.  So:
+    //   * the first stream that renders on a device owns overlapping there; once any other stream renders on that device,
+    //     overlapping is off there for the rest of the process (for everybody: mixing overlapped and plain launches across
+    //     streams stalls too, and so does handing the internal streams to a second caller stream even on an idle device);
+    //   * a priority stream gets its short launches on that stream itself, one after the other.
+    // Without overlap (the behaviour of overlap_frames = 1) the library adds no queue of its own to the caller's.
+    const int lf = s->tuning.launch_frames < frame_count ? s->tuning.launch_frames : frame_count;
+    bool overlap = false;
+    if (s->device >= 0 && s->device < kMaxDevices) {
+        std::lock_guard<std::mutex> lock(g_overlap_mutex);
+        OverlapOwner& g = g_overlap[s->device];
+        if (!g.has_owner) g.owner = (hipStream_t)stream, g.has_owner = true;
+        if (g.owner != (hipStream_t)stream) g.disabled = true;
+        overlap = !g.disabled && lf < s->tuning.overlap_frames;
+    }
+    if (overlap && stream) {
+        int prio = 0;
+        if (hipStreamGetPriority((hipStream_t)stream, &prio) != hipSuccess || prio != 0) overlap = false;
+        (void)hipGetLastError();
+    }
     Workspace ws;
-    rc = scene_workspace(s, d, frame_count, &ws, true);
+    rc = scene_workspace(s, d, frame_count, &ws, overlap);
     if (rc != RT_OK) return rc;
     return launch_render<false>(s, d, frame_begin, frame_count, accum_dev, nullptr, (hipStream_t)stream, ws);
 }
@@ -1663,7 +1709,20 @@ int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_beg
     ws.slot[0].samples = (float*)(base + off);
     ws.launch_frames = (int)lf;
     ws.timed = false;  // hipEventCreate allocates
-    return launch_render<false>(s, d, frame_begin, frame_count, accum_dev, nullptr, (hipStream_t)stream, ws);
+    // one call at a time per GPU: the whole enqueue under the lock, the device side through the guard event
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    const int dv = s->device;
+    if (g_scratch_used[dv] && g_scratch_stream[dv] != (hipStream_t)stream) {
+        const hipError_t q = hipEventQuery(g_scratch_done[dv]);
+        if (q == hipErrorNotReady)
+            return set_error(RT_ERR_INVALID_ARG, "rt_render_device_noalloc: the static scratch of device %d is still in use by a call on another stream (calls on one GPU share it: serialise them)", dv);
+        if (q != hipSuccess) return set_error(RT_ERR_HIP, "rt_render_device_noalloc: hipEventQuery: %s", hipGetErrorString(q));
+    }
+    rc = launch_render<false>(s, d, frame_begin, frame_count, accum_dev, nullptr, (hipStream_t)stream, ws);
+    if (rc != RT_OK) return rc;
+    HIPCHK(hipEventRecord(g_scratch_done[dv], (hipStream_t)stream));
+    g_scratch_used[dv] = true, g_scratch_stream[dv] = (hipStream_t)stream;
+    return RT_OK;
 }
 
 int rt_render(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_host) {

@@ -879,6 +879,106 @@ def test_one_frame_calls_overlap_and_stay_bit_exact(scene_chap5, hdr_pair):
     _assert_images_equal(bufs[0].cpu().numpy(), b, "one call cut into 14 overlapped launches")
 
 
+def test_long_call_then_one_frame_calls_share_workspace_slot_in_order(scene_chap5, hdr_pair):
+    """A 64-frame call (slot 0 of the scene's workspace, kernel + fold on the caller's stream) followed WITHOUT a
+    synchronisation by one-frame calls (overlapped: their kernels run on the internal streams and reuse slot 0's queue counters,
+    Sobol table and sample buffer): the internal stream must wait for the long call's fold.  64 + 4 x 1 frames == one 68-frame
+    call, to the bit; then the other direction (short calls, then a long one) the same."""
+    import torch
+    tris, nodes = scene_chap5
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache, device=0)
+    eye, cam = rt.camera(0.0, 20.0, 4.0)
+    W, H = 1920, 1080
+    d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+    st = torch.cuda.current_stream().cuda_stream
+    a, b, c = (torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0") for _ in range(3))
+    sc.set_tuning(launch_frames=68)
+    sc.render_device(d, 0, 68, b.data_ptr(), st)
+    torch.cuda.synchronize()
+    sc.set_tuning(launch_frames=64)
+    sc.render_device(d, 0, 64, a.data_ptr(), st)
+    for f in range(64, 68):
+        sc.render_device(d, f, 1, a.data_ptr(), st)
+    for f in range(0, 4):
+        sc.render_device(d, f, 1, c.data_ptr(), st)
+    sc.render_device(d, 4, 64, c.data_ptr(), st)
+    torch.cuda.synchronize()
+    _assert_images_equal(a.cpu().numpy(), b.cpu().numpy(), "64-frame call + 4 one-frame calls vs one call")
+    _assert_images_equal(c.cpu().numpy(), b.cpu().numpy(), "4 one-frame calls + 64-frame call vs one call")
+
+
+def test_entry_bvh_only_sees_triangles_the_callers_bvh_reaches(scene_small, hdr_pair):
+    """The caller's BVH alone decides what can be hit: triangles of the array that no reachable leaf references are never tested
+    by the reference (f5:243-256).  A BVH over the first part of the array, a wall of extra triangles in front of the camera
+    in the rest, entry BVH forced on: the wall is invisible, image / statistics / primary hits equal the oracle's."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    eye, cam = rt.camera(20.0, 15.0, 3.5)
+    e = np.asarray(eye, np.float64)
+    fwd = -e / np.linalg.norm(e)
+    up = np.array([0.0, 1.0, 0.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    up2 = np.cross(right, fwd)
+    ctr = e + 1.0 * fwd  # one unit in front of the eye
+    quad = [ctr + 3 * (sx * right + sy * up2) for sx, sy in ((-1, -1), (1, -1), (1, 1), (-1, 1))]
+    extra = np.zeros((1200, 36), np.float32)
+    for k in range(1200):  # (>= 1024 triangles in total either way; many copies at slightly different depths)
+        q = [v + 1e-3 * k * fwd for v in quad]
+        i0, i1, i2 = ((0, 1, 2), (0, 2, 3))[k % 2]
+        extra[k, 0:3], extra[k, 3:6], extra[k, 6:9] = q[i0], q[i1], q[i2]
+        extra[k, 9:18] = np.tile(-fwd, 3)
+    extra[:, 18:36] = rt.Material(baseColor=(1.0, 0.0, 0.0), emissive=(5.0, 0.0, 0.0)).as_array()
+    all_tris = np.concatenate([np.asarray(tris, np.float32).reshape(-1, 36), extra], 0)
+    for entry in (1, 0):
+        sc = rt.Scene(all_tris, nodes, hdr, cache, entry_bvh=entry)
+        assert sc.info().entry_bvh == entry
+        W, H, F = 96, 80, 3
+        d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+        ref, ost = O.render(all_tris, nodes, hdr, cache, W, H, 5, eye, cam, 0, F)
+        base, _ = O.render(tris, nodes, hdr, cache, W, H, 5, eye, cam, 0, F)
+        _assert_images_equal(ref, base, "oracle: unreferenced triangles are invisible")
+        _assert_images_equal(sc.render(d, 0, F), ref, f"unreferenced triangles, entry_bvh={entry}")
+        assert sc.render_stats(d, 0, F) == ost
+        tri, dist = sc.primary_hits(d)
+        otri, odist = O.primary_hits(all_tris, nodes, W, H, eye, cam)
+        assert np.array_equal(tri, otri) and np.array_equal(_bits(dist), _bits(odist))
+    # leaves that share triangles: no single "leaf of the hit" to climb from, so no entry BVH is built even when asked for
+    nodes2 = nodes.copy()
+    leaves = [i for i in range(1, nodes2.shape[0]) if nodes2[i, 3] > 0]
+    nodes2[leaves[1], 4] = nodes2[leaves[0], 4]  # second leaf now starts where the first one does
+    nodes2[leaves[1], 3] = 1
+    sc = rt.Scene(tris, nodes2, hdr, cache, entry_bvh=1)
+    assert sc.info().entry_bvh == 0
+    d = rt.make_desc(64, 48, mode=5, eye=eye, camera_rotate=cam)
+    ref, ost = O.render(tris, nodes2, hdr, cache, 64, 48, 5, eye, cam, 0, 2)
+    _assert_images_equal(sc.render(d, 0, 2), ref, "overlapping leaves")
+
+
+@pytest.mark.parametrize("mode,scene,up", [(5, "scene_chap5", 20.0), (4, "scene_chap4", 0.0)])
+def test_full_size_kernel_vs_libm_oracle_statistical(request, hdr_pair, mode, scene, up):
+    """The one check on the GPU box whose checker does not share the build's fixed transcendental sequences (rt_detmath.h):
+    the kernel at 1920x1080 x 64 frames against the oracle run with libm sin/cos/atan2/asin/log/pow/exp.  The reference's GLSL
+    built-ins are driver-defined, so this is the statistical bar: tone-mapped RMSE <= 0.02, relative mean <= 1 %."""
+    tris, nodes = request.getfixturevalue(scene)
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(0.0, up, 4.0)
+    W, H, F = 1920, 1080, 64
+    d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam)
+    img = sc.render(d, 0, F)
+    lib, _ = O.render(tris, nodes, hdr, cache, W, H, mode, eye, cam, 0, F, use_libm=True)
+    a = rt.tonemap_rgb8(img).astype(np.float64) / 255.0
+    b = rt.tonemap_rgb8(lib).astype(np.float64) / 255.0
+    rmse = float(np.sqrt(np.mean((a - b) ** 2)))
+    fin = np.isfinite(img) & np.isfinite(lib)
+    rel = abs(img[fin].mean() - lib[fin].mean()) / abs(lib[fin].mean())
+    print(f"mode {mode}: tone-mapped RMSE {rmse:.5f}, relative mean {rel:.5%}, differing floats {(img != lib).mean():.4%}")
+    assert fin.mean() > 0.999
+    assert rmse <= 0.02 and rel <= 0.01
+
+
 def test_render_multi_replicas_in_one_process(scene_small, hdr_pair):
     """rt_render_multi: three replicas of the scene (here all on the box's one GPU; one per device in production) render disjoint
     frame ranges concurrently and their SUM buffers are added in replica order: two steps of it equal the oracle's sums added in

@@ -33,9 +33,11 @@ def test_noalloc_equals_render_device_two_calls_second_smaller(scene_small, hdr_
     hdr, cache = hdr_pair
     sc = rt.Scene(tris, nodes, hdr, cache, device=0)
     eye, cam = rt.camera(20.0, 15.0, 3.5)
-    # first call: a large input (several launches: 40 frames > the 32 per launch); second: a smaller one on the same GPU's
-    # scratch, which still holds the first call's queue counters, Sobol pairs and samples
-    for (W, H, mode, fb, fc) in ((333, 187, 5, 3, 40), (61, 45, 5, 0, 3), (40, 24, 4, 7, 2)):
+    # first call: a large input; second: a smaller one on the same GPU's scratch, which still holds the first call's queue
+    # counters, Sobol pairs and samples.  launch_frames = 3 cuts the 40-frame call into 14 launches that reuse the one scratch
+    # slot back to back on the caller's stream; the 1080p call is cut by the scratch itself (room for 2 frames of samples)
+    for (W, H, mode, fb, fc, lf) in ((333, 187, 5, 3, 40, 3), (333, 187, 5, 3, 40, 64), (1920, 1080, 5, 1, 5, 64), (61, 45, 5, 0, 3, 64), (40, 24, 4, 7, 2, 64)):
+        sc.set_tuning(launch_frames=lf)
         d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam)
         a, b = _both(sc, d, fb, fc, torch, dev)
         A, B = _bits(a), _bits(b)
@@ -92,3 +94,31 @@ def test_noalloc_rejects_what_does_not_fit(scene_small, hdr_pair):
     with pytest.raises(rt.RtError) as e:
         sc.render_device_noalloc(d, 0, 1, buf.data_ptr(), 0)
     assert e.value.code == -1 and "scratch" in str(e.value)
+
+
+def test_noalloc_refuses_a_call_that_would_overlap_on_another_stream(scene_chap5, hdr_pair):
+    """All calls on a GPU share its scratch array.  A call on another stream while the previous call's work is still in flight
+    is refused (RT_ERR_INVALID_ARG) instead of racing; the same stream (ordered) and a later call (finished) are accepted, and
+    the library allocates no device memory in any of them."""
+    import torch
+    dev = torch.device("cuda", 0)
+    tris, nodes = scene_chap5
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache, device=0)
+    eye, cam = rt.camera(0.0, 20.0, 4.0)
+    d = rt.make_desc(1920, 1080, mode=5, eye=eye, camera_rotate=cam)
+    a = torch.zeros((1080, 1920, 3), dtype=torch.float32, device=dev)
+    b = torch.zeros_like(a)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    sc.render_device_noalloc(d, 0, 16, a.data_ptr(), s1.cuda_stream)      # ~10 ms of GPU work in flight
+    with pytest.raises(rt.RtError) as e:
+        sc.render_device_noalloc(d, 0, 1, b.data_ptr(), s2.cuda_stream)
+    assert e.value.code == -1 and "in use" in str(e.value)
+    sc.render_device_noalloc(d, 16, 1, a.data_ptr(), s1.cuda_stream)      # same stream: ordered behind the first call
+    torch.cuda.synchronize(dev)
+    sc.render_device_noalloc(d, 0, 17, b.data_ptr(), s2.cuda_stream)      # the scratch is free again
+    torch.cuda.synchronize(dev)
+    assert torch.cuda.mem_get_info(dev)[0] == free0                        # hipMemGetInfo: nothing was allocated on the device
+    assert np.array_equal(_bits(a), _bits(b))
