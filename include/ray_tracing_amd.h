@@ -214,6 +214,11 @@ typedef struct rt_tuning {
                                   builds a private binned-SAH tree over the same triangles; a ray walks it first, with a
                                   conservative box test, to get a distance bound or to prove it hits nothing, and the caller's
                                   BVH — which alone decides the result — only inside that bound.  Same images, fewer nodes. */
+    int32_t single_kernel;     /* > 0: the whole path loop in one kernel.  Default 0: two kernels per launch where the workspace
+                                  allows it (no entry BVH, BVH depth <= 18): the camera rays of all samples — coherent work — are
+                                  traced first by a plain one-lane-per-pixel kernel that also finishes the samples that escape and
+                                  leaves 64-byte path states (8.5 GB per 64-frame 1080p launch) from which the wave-scheduled
+                                  path loop continues.  Same images to the bit. */
 } rt_tuning;
 int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out);
 int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t);
@@ -261,9 +266,10 @@ int rt_kernel_time_ms(float* avg_ms, int* launches, int reset);
  * launches of ONE shape on `s` (the calling thread's timed launches since the last reset are assumed to be that
  * scene's).  Synchronises the device. */
 typedef struct rt_kernel_timing_info {
-    float avg_ms, max_ms;
+    float avg_ms, max_ms;      /* the path-loop kernel (render_kernel) */
     int32_t launches;
     float shader_clock_mhz;
+    float first_avg_ms;        /* two-kernel form: average duration of the camera-ray kernel (first_kernel) that precedes it; else 0 */
 } rt_kernel_timing_info;
 int rt_kernel_timing(rt_scene* s, rt_kernel_timing_info* out, int reset);
 

@@ -91,7 +91,7 @@ class TraceStats(C.Structure):
 
 class Tuning(C.Structure):
     """rt_tuning: scheduling knobs of the path loop (they never change the image)."""
-    _fields_ = [(n, C.c_int32) for n in ("launch_frames", "unit_frames", "leaf_lanes", "shade_lanes", "wait_budget", "no_cull", "overlap_frames", "no_entry_bvh")]
+    _fields_ = [(n, C.c_int32) for n in ("launch_frames", "unit_frames", "leaf_lanes", "shade_lanes", "wait_budget", "no_cull", "overlap_frames", "no_entry_bvh", "single_kernel")]
 
 
 class SceneInfo(C.Structure):
@@ -103,7 +103,7 @@ class SceneInfo(C.Structure):
 
 class KernelTiming(C.Structure):
     """rt_kernel_timing_info."""
-    _fields_ = [("avg_ms", C.c_float), ("max_ms", C.c_float), ("launches", C.c_int32), ("shader_clock_mhz", C.c_float)]
+    _fields_ = [("avg_ms", C.c_float), ("max_ms", C.c_float), ("launches", C.c_int32), ("shader_clock_mhz", C.c_float), ("first_avg_ms", C.c_float)]
 
 
 class RtError(RuntimeError):

@@ -117,24 +117,29 @@ struct RenderParams {
     int wait_budget;       // lane-passes spent waiting for the shade pass that trigger it
     int32_t* hit_tri;      // primary-hit query outputs
     float* hit_dist;
+    // two-kernel form of the path loop (first_kernel -> render_kernel<..., SEG>):
+    float4* states;        // per unit (tile, frame group) a region of unit_frames x 64 path states (4 x float4 each), filled from its start
+    int* unit_count;       // per unit: how many states first_kernel left there
+    float2* cp;            // per pixel: the Cranley-Patterson shift (f5:367-383)
 };
 
 struct LaneStack {
-    int* lds;              // &s_stack[threadIdx.x]; entry k at lds[k * kBlock]
+    int* lds;              // &s_stack[threadIdx.x]; entry k at lds[k * lstride]
     int* spill;            // &spill[global thread]; entry k at spill[(k - kLdsDepth) * stride]
     long long stride;
+    int lstride;           // threads of the workgroup (the LDS part is laid out [depth][thread])
 };
 
 template <bool SPILL>
 __device__ __forceinline__ void stack_push(const LaneStack& st, int sp, int v) {
     if (!SPILL || sp < kLdsDepth)
-        st.lds[sp * kBlock] = v;
+        st.lds[sp * st.lstride] = v;
     else
         st.spill[(long long)(sp - kLdsDepth) * st.stride] = v;
 }
 template <bool SPILL>
 __device__ __forceinline__ int stack_pop(const LaneStack& st, int sp) {
-    if (!SPILL || sp < kLdsDepth) return st.lds[sp * kBlock];
+    if (!SPILL || sp < kLdsDepth) return st.lds[sp * st.lstride];
     return st.spill[(long long)(sp - kLdsDepth) * st.stride];
 }
 
@@ -143,8 +148,8 @@ enum TieRule { TIE_SHADER = 0, TIE_CHAP2 = 1 };
 // ---- T3/T4: hitArray + hitBVH, f5:243-311 (TIE_SHADER) / c2:451-513 (TIE_CHAP2) --------------------------------
 // Returns the closest triangle index (-1 = miss) and its distance.  ANYHIT returns at the first accepted hit.
 template <bool ANYHIT, int TIE, bool STATS, bool SPILL>
-__device__ __forceinline__ int hitBVH(const DevScene& sc, const LaneStack& stk, vec3 S, vec3 d, float* dist, Stats& st) {
-    constexpr bool CULL = !STATS && !ANYHIT;  // statistics builds walk exactly the reference's nodes
+__device__ __forceinline__ int hitBVH(const DevScene& sc, const LaneStack& stk, vec3 S, vec3 d, float* dist, Stats& st, bool stats_executed = false) {
+    const bool CULL = !ANYHIT && (!STATS || stats_executed);  // statistics builds walk exactly the reference's nodes unless asked for the executed walk
     float best = INF_;
     int best_tri = -1;
     int best_first = -1;
@@ -350,7 +355,8 @@ constexpr int kMaxLaunchFrames = 1024;  // bound of RT_AMD_CHUNK (sizes the per-
 constexpr int kLaunchFrames = 64;  // frames per kernel launch (sample buffer = W x H x frames x 12 B = 1.6 GB at 1080p; a launch
                                    // ramps up and drains for ~0.5 ms whatever its length: 32 -> 64 frames = +2.8 %, 128: +4.2 %)
 constexpr int kUnitFrames = 2;     // frames per work unit (one 8x8 tile x this many frames = 128 samples)
-constexpr size_t kMaxSampleBytes = (size_t)8 << 30;  // 4K x 64 frames x 12 B = 6.4 GB fits (288 GB of HBM)
+constexpr size_t kMaxSampleBytes = (size_t)12 << 30;  // per-launch workspace: samples (W x H x frames x 12 B) + in the two-kernel form the
+                                                      // path states (64 B per sample slot): 1080p x 64 frames = 1.6 + 8.5 GB (288 GB of HBM)
 constexpr int kMaxWidth = 65535, kMaxHeight = 32767;  // a pixel travels as (x | y << 16) in one int
 constexpr int kOverlapFrames = 8;  // launches of fewer frames overlap their neighbours (two workspace slots, internal streams)
 constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
@@ -380,7 +386,11 @@ __device__ __forceinline__ int wave_inclusive_sum(int x) {
     return x;
 }
 
-template <int MODE, bool STATS, bool SPILL, bool ENTRY>
+// SEG: the two-kernel form.  first_kernel (below) has traced every sample's camera ray — coherent work: the 64 rays of an 8x8
+// tile walk the same nodes — written the samples that ended there, and left, per unit, the states of the paths that go on.  This
+// kernel's work items are then those states (a surface point with its first secondary ray, or K_NONE), not (pixel, frame) pairs:
+// no K_PRIMARY rays, no camera-ray code, and the Cranley-Patterson shift comes from a per-pixel table instead of two registers.
+template <int MODE, bool STATS, bool SPILL, bool ENTRY, bool SEG>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU))) render_kernel(const RenderParams P) {
     __shared__ int s_stack[kLdsDepth * kWave];        // per-lane traversal stacks, [depth][lane]
     __shared__ float4 s_ray[2 * kWave];                // per lane: the ray in flight (S.xyz, d.x) (d.yz, phase, primary-hit triangle of the path)
@@ -458,8 +468,10 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     // free, and takes the next unit while its last paths are still in flight — so no lane waits for a neighbour's longer
     // path and every wave runs until the queue is empty.  Samples go to the launch's sample buffer; fold_kernel then
     // applies f5:954-955 per pixel in frame order, which keeps the fp32 running mean exact.
-    int unit_tx0 = 0, unit_ty0 = 0, unit_f0 = 0;  // wave-uniform: the unit being handed out
+    int unit_tx0 = 0, unit_ty0 = 0, unit_f0 = 0;  // wave-uniform: the unit being handed out (SEG: unit_f0 = its first state slot)
     int unit_items = 0, next_item = 0;            // its size and the first item not handed out yet
+    bool pend_fin = false;          // the path ended in the BRDF-sampling step, after this pass's end-of-sample step: its sample is
+                                    // stored (and the lane refilled) by the next shade pass
     bool queue_empty = false;
     unsigned open_bands = 0xffu;                  // wave-uniform: tile bands (one per XCD) that may still have units
     bool need_new = true;           // every lane asks for its first sample in the prologue pass
@@ -474,8 +486,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             // ---- the shade pass: every lane whose ray came back (primary / env-visibility / BRDF ray, told apart by
             // `kind`), step by step; a step runs once for all lanes that need it ------------------------------------
             bool to_B = false, to_C = false, fin = false, emit = false;
-            const bool h = (op == OP_H);
-            const bool isA = h && KIND_ == K_PRIMARY, isD = h && KIND_ == K_BOUNCE;
+            const bool h = (op == OP_H) && !pend_fin;
+            const bool isA = !SEG && h && KIND_ == K_PRIMARY, isD = h && KIND_ == K_BOUNCE;
             const bool isC = h && (KIND_ == K_SHADOW || KIND_ == K_NONE);
             const bool miss = best_tri < 0;
             const vec3 L = d;  // direction of the ray that came back
@@ -581,8 +593,121 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 hitP = nh.hitPoint, N = nh.normal, V = -nh.viewDir, surf_tri = best_tri;
                 if (BOUNCE_ < P.max_bounce) to_B = true; else fin = true;
             }
-            // ---- start of a bounce (f5:856-866 env sample; chapters 3/4: the hemisphere sample) ------------------
+            // ---- end of a sample: Le + Li (f5:950) goes to the launch's sample buffer ----------------------------------
             SHADE_MARK(3);  // finish hit
+            if (pend_fin) fin = true, pend_fin = false;
+            if (STATS) { const int c_ = __popcll(__ballot(fin)); if (lane == 0) sg[5] += c_; }
+            if (fin) {
+                vec3 sample = Lo;
+                const int first_tri = __float_as_int(s_ray[2 * lane + 1].w);
+                if (first_tri >= 0) {
+                    const float* T = sc.tris + (size_t)first_tri * 36 + 18;
+                    sample = v3(T[0], T[1], T[2]) + Lo;
+                }
+                float* o = P.samples + ((size_t)FIDX_ * n_pixels + (size_t)(pxy >> 16) * P.width + (pxy & 0xffff)) * 3;
+                o[0] = sample.x, o[1] = sample.y, o[2] = sample.z;
+                if (STATS) paths++;
+                need_new = true;
+            }
+            // ---- next work item: hand out the unit's remaining items in order, taking the next unit from the queue when it runs
+            // out.  One-kernel form: items are the unit's (frame, pixel) pairs (pixels outside the image are skipped), followed by
+            // seed, jitter, camera ray (f5:320-323, 932-937).  SEG: items are the path states first_kernel left in the unit's region --
+            bool got = false;
+            int slot = 0;
+            for (;;) {
+                const unsigned long long asking = __ballot(need_new && !got);
+                if (asking == 0ull) break;  // wave-uniform
+                if (next_item >= unit_items) {
+                    if (queue_empty) break;
+                    // take a unit: from this XCD's band of tiles first (neighbouring tiles walk the same nodes, and each
+                    // XCD has its own L2), then from the next band that still has work
+                    int tile = 0, group = 0;
+                    bool have = false;
+                    while (open_bands != 0u) {
+                        const int q = (xcd + __builtin_ctz(((open_bands >> xcd) | (open_bands << (8 - xcd))) & 0xffu)) & 7;
+                        const int band_begin = (int)((long long)n_tiles * q / 8), band_tiles = (int)((long long)n_tiles * (q + 1) / 8) - band_begin;
+                        unsigned u = 0;
+                        if (lane == 0) u = __hip_atomic_fetch_add(P.queue + q * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        u = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
+                        if (SEG) {
+                            // (a unit in which no path goes on — every sample ended at its camera ray — is taken like any other and
+                            // left at once; handing out only the non-empty ones through a compacted list was measured: the list's
+                            // atomics cost 0.5 ms per launch and the path loop ran 40 % slower, not faster)
+                            if (u < (unsigned)band_tiles * (unsigned)n_groups) {
+                                const int t_ = band_begin + (int)(u % (unsigned)band_tiles), g_ = (int)(u / (unsigned)band_tiles);
+                                tile = g_ * n_tiles + t_;  // first_kernel's block number
+                                group = __builtin_amdgcn_readfirstlane(P.unit_count[tile]);
+                                have = true;
+                                break;
+                            }
+                        } else if (u < (unsigned)band_tiles * (unsigned)n_groups) {
+                            tile = band_begin + (int)(u % (unsigned)band_tiles), group = (int)(u / (unsigned)band_tiles);
+                            have = true;
+                            break;
+                        }
+                        open_bands &= ~(1u << q);  // that band is handed out completely
+                    }
+                    if (!have) {
+                        queue_empty = true;
+                        break;
+                    }
+                    if (SEG) {
+                        unit_f0 = tile * (P.unit_frames * kWave), unit_items = group, next_item = 0;  // (its region of `states`, its count)
+                        if (unit_items == 0) continue;
+                    } else {
+                        unit_tx0 = (tile % tilesx) * 8, unit_ty0 = (tile / tilesx) * 8, unit_f0 = group * P.unit_frames;
+                        const int nf = P.frame_count - unit_f0 < P.unit_frames ? P.frame_count - unit_f0 : P.unit_frames;
+                        unit_items = nf * kWave, next_item = 0;
+                    }
+                }
+                if (need_new && !got) {
+                    const int it = next_item + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(asking >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)asking, 0u));
+                    if (it < unit_items) {
+                        if (SEG) {
+                            slot = unit_f0 + it, got = true;
+                        } else {
+                            const int ix = unit_tx0 + (it & 7), iy = unit_ty0 + ((it >> 3) & 7);
+                            pxy = ix | (iy << 16), fbk = (fbk & ~1023u) | (unsigned)(unit_f0 + (it >> 6));
+                            got = ix < P.width && iy < P.height;
+                        }
+                    }
+                }
+                next_item += __popcll(asking);
+            }
+            if (need_new) {
+                need_new = false;
+                if (!got) {
+                    op = OP_DONE;  // the queue is empty
+                } else if (SEG) {
+                    const float4* rec = P.states + (size_t)(unsigned)slot * 4;
+                    const float4 ra = rec[0], rb = rec[1], rc = rec[2], re = rec[3];
+                    hitP = v3(ra.x, ra.y, ra.z), N = v3(rb.z, rb.w, rc.x), V = v3(rc.y, rc.z, rc.w);
+                    seed = __float_as_uint(re.x), pxy = __float_as_int(re.y), fbk = __float_as_uint(re.z), surf_tri = __float_as_int(re.w);
+                    s_ray[2 * lane + 1].w = re.w;  // the primary hit = the first surface point
+                    Lo = v3(0), history = v3(1);
+                    if (KIND_ == K_NONE) {
+                        to_C = true;  // no env-visibility ray for this point (f5:863): straight to BRDF sampling
+                    } else {
+                        S = hitP, d = v3(ra.w, rb.x, rb.y), emit = true;
+                    }
+                } else {
+                    const float pixx = -1.0f + 2.0f * ((float)(pxy & 0xffff) + 0.5f) / (float)P.width;
+                    const float pixy = -1.0f + 2.0f * ((float)(pxy >> 16) + 0.5f) / (float)P.height;
+                    if (MODE == RT_MODE_CHAP5) cp_shift(pixx, pixy, P.width, P.height, &cpu, &cpv);
+                    seed = pixel_seed(pixx, pixy, P.width, P.height, (unsigned)(P.frame_begin + FIDX_));
+                    const float aax = (rand01(seed) - 0.5f) / (float)P.width;
+                    const float aay = (rand01(seed) - 0.5f) / (float)P.height;
+                    const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
+                    const float* m = P.cam;  // column-major: m[col*4+row]
+                    vec3 dir;
+                    dir.x = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
+                    dir.y = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
+                    dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
+                    S = v3(P.eye[0], P.eye[1], P.eye[2]), d = normalize(dir), SET_KIND_(K_PRIMARY), emit = true;
+                }
+            }
+            // ---- start of a bounce (f5:856-866 env sample; chapters 3/4: the hemisphere sample) ------------------
+            SHADE_MARK(6);  // end of sample + next work item (+ camera ray)
             if (STATS) { const int c_ = __popcll(__ballot(to_B)); if (lane == 0) sg[3] += c_; }
             if (to_B) {
                 if (MODE == RT_MODE_CHAP5) {
@@ -607,97 +732,23 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
             if (MODE == RT_MODE_CHAP5 && (isC || to_C)) {
                 const MatPre pre = load_mat_pre(sc, surf_tri);
                 const float2 sb = P.sobol[FIDX_ * 4 + BOUNCE_];  // sobolVec2(frameCounter + 1, bounce): depends on (frame, bounce) only
-                const float xi_1 = cp_rotate(sb.x, cpu);
-                const float xi_2 = cp_rotate(sb.y, cpv);
+                float su = cpu, sv = cpv;
+                if (SEG) {
+                    const float2 cs = P.cp[(size_t)(pxy >> 16) * P.width + (pxy & 0xffff)];
+                    su = cs.x, sv = cs.y;
+                }
+                const float xi_1 = cp_rotate(sb.x, su);
+                const float xi_2 = cp_rotate(sb.y, sv);
                 const float xi_3 = rand01(seed);
                 const vec3 Ls = SampleBRDF_pre(xi_1, xi_2, xi_3, V, N, pre);
                 if (dot(N, Ls) <= 0.0f) {
-                    fin = true;
+                    pend_fin = true, op = OP_H;  // f5:891: the path ends; the next shade pass stores its sample
                 } else {
                     S = hitP, d = Ls, SET_KIND_(K_BOUNCE), emit = true;
                 }
             }
-            // ---- end of a sample: Le + Li (f5:950) goes to the launch's sample buffer ----------------------------------
             SHADE_MARK(5);  // BRDF sampling
-            if (STATS) { const int c_ = __popcll(__ballot(fin)); if (lane == 0) sg[5] += c_; }
-            if (fin) {
-                vec3 sample = Lo;
-                const int first_tri = __float_as_int(s_ray[2 * lane + 1].w);
-                if (first_tri >= 0) {
-                    const float* T = sc.tris + (size_t)first_tri * 36 + 18;
-                    sample = v3(T[0], T[1], T[2]) + Lo;
-                }
-                float* o = P.samples + ((size_t)FIDX_ * n_pixels + (size_t)(pxy >> 16) * P.width + (pxy & 0xffff)) * 3;
-                o[0] = sample.x, o[1] = sample.y, o[2] = sample.z;
-                if (STATS) paths++;
-                need_new = true;
-            }
-            // ---- next sample: hand out the unit's remaining (frame, pixel) items in order, taking the next unit from the
-            // queue when it runs out; pixels outside the image are skipped.  Then seed, jitter, camera ray (f5:320-323,
-            // 932-937) --------------------------------------------------------------------------------------------------
-            bool got = false;
-            for (;;) {
-                const unsigned long long asking = __ballot(need_new && !got);
-                if (asking == 0ull) break;  // wave-uniform
-                if (next_item >= unit_items) {
-                    if (queue_empty) break;
-                    // take a unit: from this XCD's band of tiles first (neighbouring tiles walk the same nodes, and each
-                    // XCD has its own L2), then from the next band that still has work
-                    int tile = 0, group = 0;
-                    bool have = false;
-                    while (open_bands != 0u) {
-                        const int q = (xcd + __builtin_ctz(((open_bands >> xcd) | (open_bands << (8 - xcd))) & 0xffu)) & 7;
-                        const int band_begin = (int)((long long)n_tiles * q / 8), band_tiles = (int)((long long)n_tiles * (q + 1) / 8) - band_begin;
-                        unsigned u = 0;
-                        if (lane == 0) u = __hip_atomic_fetch_add(P.queue + q * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        u = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
-                        if (u < (unsigned)band_tiles * (unsigned)n_groups) {
-                            tile = band_begin + (int)(u % (unsigned)band_tiles), group = (int)(u / (unsigned)band_tiles);
-                            have = true;
-                            break;
-                        }
-                        open_bands &= ~(1u << q);  // that band is handed out completely
-                    }
-                    if (!have) {
-                        queue_empty = true;
-                        break;
-                    }
-                    unit_tx0 = (tile % tilesx) * 8, unit_ty0 = (tile / tilesx) * 8, unit_f0 = group * P.unit_frames;
-                    const int nf = P.frame_count - unit_f0 < P.unit_frames ? P.frame_count - unit_f0 : P.unit_frames;
-                    unit_items = nf * kWave, next_item = 0;
-                }
-                if (need_new && !got) {
-                    const int it = next_item + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(asking >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)asking, 0u));
-                    if (it < unit_items) {
-                        const int ix = unit_tx0 + (it & 7), iy = unit_ty0 + ((it >> 3) & 7);
-                        pxy = ix | (iy << 16), fbk = (fbk & ~1023u) | (unsigned)(unit_f0 + (it >> 6));
-                        got = ix < P.width && iy < P.height;
-                    }
-                }
-                next_item += __popcll(asking);
-            }
-            if (need_new) {
-                need_new = false;
-                if (!got) {
-                    op = OP_DONE;  // the queue is empty
-                } else {
-                    const float pixx = -1.0f + 2.0f * ((float)(pxy & 0xffff) + 0.5f) / (float)P.width;
-                    const float pixy = -1.0f + 2.0f * ((float)(pxy >> 16) + 0.5f) / (float)P.height;
-                    if (MODE == RT_MODE_CHAP5) cp_shift(pixx, pixy, P.width, P.height, &cpu, &cpv);
-                    seed = pixel_seed(pixx, pixy, P.width, P.height, (unsigned)(P.frame_begin + FIDX_));
-                    const float aax = (rand01(seed) - 0.5f) / (float)P.width;
-                    const float aay = (rand01(seed) - 0.5f) / (float)P.height;
-                    const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
-                    const float* m = P.cam;  // column-major: m[col*4+row]
-                    vec3 dir;
-                    dir.x = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
-                    dir.y = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
-                    dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
-                    S = v3(P.eye[0], P.eye[1], P.eye[2]), d = normalize(dir), SET_KIND_(K_PRIMARY), emit = true;
-                }
-            }
             // ---- hitBVH prologue (f5:260-268) --------------------------------------------------------------------
-            SHADE_MARK(6);  // end of sample + next sample + camera ray
             if (STATS) { const int c_ = __popcll(__ballot(emit)); if (lane == 0) sg[6] += c_; }
             if (emit) {
                 if (STATS) st.rays++;
@@ -1004,6 +1055,116 @@ __global__ void __launch_bounds__(128) sobol_table_kernel(float2* out, int frame
     out[t] = make_float2(sobol_dim(d_sobolV, 2 * (t & 3), gray), sobol_dim(d_sobolV, 2 * (t & 3) + 1, gray));
 }
 
+// CranleyPattersonRotation's per-pixel shift (f5:367-383) for every pixel of the image (two-kernel form: the BRDF-sampling step
+// gathers it instead of carrying two registers through the whole path).
+__global__ void __launch_bounds__(256) cp_table_kernel(float2* out, int width, int height) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (size_t)width * height) return;
+    const int ix = (int)(p % (size_t)width), iy = (int)(p / (size_t)width);
+    const float pixx = -1.0f + 2.0f * ((float)ix + 0.5f) / (float)width;
+    const float pixy = -1.0f + 2.0f * ((float)iy + 0.5f) / (float)height;
+    float u, v;
+    cp_shift(pixx, pixy, width, height, &u, &v);
+    out[p] = make_float2(u, v);
+}
+
+// ---- the first segment of every path: camera ray, closest hit, what follows up to the first secondary ray ------------------
+// fshader.fsh main() up to its first hitBVH result (f5:926-951; f4:545-566; f3) and the start of bounce 0 (f5:856-866 / f4:513).
+// One wave = one unit (an 8x8 tile x unit_frames frames), one lane = one pixel, frame after frame.  The 64 camera rays of a tile
+// start at the eye and leave through neighbouring pixels: they walk the same nodes and test the same leaves, so the plain
+// per-lane loop (hitBVH above: the reference's visit order, the closest-hit cull) runs with nearly every lane busy — the work
+// the wave-scheduled path loop is worst at (it would spend an internal-node pass per node with about half its lanes idle).
+//   miss  -> the sample is the environment colour (f5:945): stored, the path is over;
+//   hit   -> the hit record (f5:205-219) and the first decision of bounce 0: chapter 5 draws the env sample (f5:862) — an
+//            env-visibility ray if it faces the surface, else K_NONE (BRDF sampling next); chapters 3/4 draw the hemisphere
+//            direction.  The state {hitPoint, next direction, N, V, seed, pixel, frame | kind, triangle} goes to the unit's
+//            region of `states`, packed from its start (ballot + mbcnt); unit_count[unit] = how many.
+// render_kernel<..., SEG> continues from those states.  Per sample the arithmetic and the RNG call order are unchanged.
+template <int MODE, bool STATS>
+__global__ void __launch_bounds__(kWave) first_kernel(const RenderParams P) {
+    __shared__ int s_stack[kLdsDepth * kWave];
+    const DevScene& sc = P.sc;
+    const int lane = threadIdx.x;
+    const int tilesx = (P.width + 7) >> 3, n_tiles = tilesx * ((P.height + 7) >> 3);
+    const int tile = (int)(blockIdx.x % (unsigned)n_tiles), group = (int)(blockIdx.x / (unsigned)n_tiles);
+    const int ix = (tile % tilesx) * 8 + (lane & 7), iy = (tile / tilesx) * 8 + (lane >> 3);
+    const bool inside = ix < P.width && iy < P.height;
+    const int f0 = group * P.unit_frames;
+    const int nf = P.frame_count - f0 < P.unit_frames ? P.frame_count - f0 : P.unit_frames;
+    LaneStack stk;
+    stk.lds = &s_stack[lane], stk.lstride = kWave, stk.spill = nullptr, stk.stride = 0;
+    Stats st = {0, 0, 0, 0, 0};
+    unsigned long long paths = 0;
+    const size_t n_pixels = (size_t)P.width * P.height;
+    float4* const region = P.states + (size_t)blockIdx.x * (size_t)(P.unit_frames * kWave) * 4;
+    const float pixx = -1.0f + 2.0f * ((float)ix + 0.5f) / (float)P.width;
+    const float pixy = -1.0f + 2.0f * ((float)iy + 0.5f) / (float)P.height;
+    const vec3 S = v3(P.eye[0], P.eye[1], P.eye[2]);
+    int count = 0;  // wave-uniform: states written so far
+    for (int k = 0; k < nf; ++k) {
+        const int fidx = f0 + k;
+        bool go_on = false;
+        float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra, re = ra;
+        if (inside) {
+            unsigned seed = pixel_seed(pixx, pixy, P.width, P.height, (unsigned)(P.frame_begin + fidx));
+            const float aax = (rand01(seed) - 0.5f) / (float)P.width;
+            const float aay = (rand01(seed) - 0.5f) / (float)P.height;
+            const float vx = pixx + aax, vy = pixy + aay, vz = -1.5f, vw = 0.0f;
+            const float* m = P.cam;  // column-major: m[col*4+row]
+            vec3 dir;
+            dir.x = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
+            dir.y = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
+            dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
+            const vec3 d = normalize(dir);
+            float t;
+            const int tri = hitBVH<false, TIE_SHADER, STATS, false>(sc, stk, S, d, &t, st, P.stats_executed != 0);
+            if (tri < 0) {
+                vec3 color = v3(0);  // f5:945 / f4:557: the environment along the camera ray
+                if (sc.hdr) {
+                    float eu, ew;
+                    toSphericalCoord(normalize(d), &eu, &ew);
+                    const float4 c = sc.hdr[texel_index(ew, sc.hdrH) * sc.hdrW + texel_index(eu, sc.hdrW)];
+                    color = v3(c.x, c.y, c.z);
+                    if (MODE != RT_MODE_CHAP5) color = min3(color, v3(10));  // f4:162
+                }
+                float* o = P.samples + ((size_t)fidx * n_pixels + (size_t)iy * P.width + ix) * 3;
+                o[0] = color.x, o[1] = color.y, o[2] = color.z;
+                if (STATS) paths++;
+            } else {
+                const Hit nh = finish_hit<MODE>(sc, S, d, tri, t);
+                const vec3 N = nh.normal;
+                vec3 dn = v3(0);
+                unsigned kind;
+                if (MODE == RT_MODE_CHAP5) {
+                    const float r1 = rand01(seed), r2 = rand01(seed);
+                    const float4 ce = sc.cdir[texel_index(r2, sc.hdrH) * sc.hdrW + texel_index(r1, sc.hdrW)];
+                    const vec3 Lh = v3(ce.x, ce.y, ce.z);
+                    if (dot(N, Lh) > 0.0f)
+                        dn = Lh, kind = K_SHADOW;
+                    else
+                        kind = K_NONE;
+                } else {
+                    dn = toNormalHemisphere(SampleHemisphereRand(seed), N), kind = K_BOUNCE;
+                }
+                go_on = true;
+                ra = make_float4(nh.hitPoint.x, nh.hitPoint.y, nh.hitPoint.z, dn.x);
+                rb = make_float4(dn.y, dn.z, N.x, N.y);
+                rc = make_float4(N.z, -d.x, -d.y, -d.z);  // V = -viewDir
+                re = make_float4(__uint_as_float(seed), __int_as_float(ix | (iy << 16)), __uint_as_float((unsigned)fidx | (kind << 30)), __int_as_float(tri));
+            }
+        }
+        const unsigned long long m = __ballot(go_on);
+        if (go_on) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            float4* o = region + (size_t)(count + rank) * 4;
+            o[0] = ra, o[1] = rb, o[2] = rc, o[3] = re;
+        }
+        count += __popcll(m);
+    }
+    if (lane == 0) P.unit_count[blockIdx.x] = count;
+    if (STATS) flush_stats(P, st, paths);
+}
+
 // The frame blend of f5:954-955 (or the plain sum of the spp-split multi-GPU mode): per pixel, over the launch's samples
 // in frame order.
 __global__ void __launch_bounds__(256) fold_kernel(const RenderParams P) {
@@ -1032,6 +1193,7 @@ __global__ void __launch_bounds__(kBlock) primary_kernel(const RenderParams P) {
     const bool active = lane_pixel(P, &px, &py);
     LaneStack stk;
     stk.lds = &s_stack[threadIdx.x];
+    stk.lstride = kBlock;
     stk.stride = P.spill_stride;
     stk.spill = SPILL ? (P.spill + ((long long)blockIdx.x * kBlock + threadIdx.x)) : nullptr;
     Stats st = {0, 0, 0, 0, 0};
@@ -1057,14 +1219,18 @@ __global__ void __launch_bounds__(kBlock) primary_kernel(const RenderParams P) {
 // ---- host side ---------------------------------------------------------------------------------------------------
 
 struct TimedLaunch {
-    hipEvent_t a, b;
+    hipEvent_t a, b;    // around the path-loop kernel (render_kernel)
+    hipEvent_t a0;      // two-kernel form: before first_kernel (a0 .. a = its duration); else NULL
 };
 static thread_local std::vector<TimedLaunch> g_launches;
+static void destroy_timed(TimedLaunch& tl) {
+    (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
+    if (tl.a0) (void)hipEventDestroy(tl.a0);
+}
 constexpr size_t kMaxTimedLaunches = 1024;  // bound on the events kept for rt_kernel_time_ms
 static void remember_launch(const TimedLaunch& tl) {
     if (g_launches.size() >= kMaxTimedLaunches) {  // nobody is reading the timings: keep the most recent half
-        for (size_t k = 0; k < kMaxTimedLaunches / 2; ++k)
-            (void)hipEventDestroy(g_launches[k].a), (void)hipEventDestroy(g_launches[k].b);
+        for (size_t k = 0; k < kMaxTimedLaunches / 2; ++k) destroy_timed(g_launches[k]);
         g_launches.erase(g_launches.begin(), g_launches.begin() + kMaxTimedLaunches / 2);
     }
     g_launches.push_back(tl);
@@ -1125,6 +1291,12 @@ struct rt_scene {
         size_t samples_bytes = 0;
         float2* d_sobol = nullptr;   // Sobol pairs of the launch's frames (kMaxLaunchFrames x 4)
         unsigned* d_queue = nullptr; // work-queue counters
+        float4* d_states = nullptr;  // two-kernel form: path states per unit, the units' state counts, the per-pixel CP shifts
+        size_t states_bytes = 0;
+        int* d_count = nullptr;
+        size_t count_bytes = 0;
+        float2* d_cp = nullptr;
+        size_t cp_bytes = 0;
         hipStream_t stream = nullptr;        // the path-loop kernel of this slot runs here
         hipEvent_t render_done = nullptr;    // recorded on `stream` after the path-loop kernel
         hipEvent_t fold_done = nullptr;      // recorded on the caller's stream after the fold that read this slot's samples
@@ -1135,7 +1307,7 @@ struct rt_scene {
     float* d_frame = nullptr;    // rt_render: device copy of the caller's host accumulation buffer
     size_t frame_bytes = 0;
     int cu_count = 0;
-    rt_tuning tuning{kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames, 0};
+    rt_tuning tuning{kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames, 0, 0};
     float cull_eps = 0.0f;       // scene part of the culling margin; +inf = the BVH / triangles do not allow culling
     void* d_nodes2 = nullptr;    // entry BVH (device-private, see host_fastbvh.cpp): records, triangles in its leaf order
     void* d_ttri2 = nullptr;
@@ -1168,6 +1340,7 @@ void rt_scene_destroy(rt_scene* s) {
     (void)hipFree(s->d_nodes2), (void)hipFree(s->d_ttri2), (void)hipFree(s->d_map2), (void)hipFree(s->d_leafx), (void)hipFree(s->d_parentx);
     for (auto& sl : s->slot) {
         (void)hipFree(sl.d_spill), (void)hipFree(sl.d_samples), (void)hipFree(sl.d_queue), (void)hipFree(sl.d_sobol);
+        (void)hipFree(sl.d_states), (void)hipFree(sl.d_count), (void)hipFree(sl.d_cp);
         if (sl.render_done) (void)hipEventDestroy(sl.render_done);
         if (sl.fold_done) (void)hipEventDestroy(sl.fold_done);
     }
@@ -1322,6 +1495,9 @@ struct WorkSlot {
     float2* sobol = nullptr;       // kMaxLaunchFrames x 4 Sobol pairs
     float* samples = nullptr;      // launch_frames x W x H x RGB
     int* spill = nullptr;          // global part of the traversal stacks (deep trees only)
+    float4* states = nullptr;      // non-NULL: the two-kernel form (first_kernel -> render_kernel<..., SEG>) ...
+    int* unit_count = nullptr;     // ... with its per-unit state counts
+    float2* cp = nullptr;          // ... and the per-pixel Cranley-Patterson shifts
     rt_scene::Slot* owner = nullptr;  // the scene's slot these buffers belong to (NULL: the static scratch): its fold_done event
                                       // orders every reuse of the buffers, whichever stream the previous user ran on
     bool own_stream = false;       // run the path-loop kernel on owner->stream (overlapped launches), else on the caller's stream
@@ -1418,6 +1594,9 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         // launch — other slot — is still draining its last paths; the fold then waits for it on the caller's stream
         const WorkSlot& w = ws.slot[ws.next_slot ? ((*ws.next_slot)++ % (unsigned)ws.n_slots) : 0];
         P.queue = w.queue, P.samples = w.samples, P.sobol = w.sobol, P.spill = w.spill;
+        P.states = w.states, P.unit_count = w.unit_count, P.cp = w.cp;
+        // two-kernel form: where the workspace has room for the path states, the tree fits the LDS stack and no entry BVH is walked
+        const bool seg = w.states != nullptr && !spill && !entry;
         const bool piped = w.owner && w.own_stream;
         const hipStream_t rstream = piped ? w.owner->stream : stream;
         // the slot's previous user — overlapped or not, on whatever stream — has folded its samples (a wait on an event
@@ -1428,6 +1607,22 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
             hipLaunchKernelGGL(sobol_table_kernel, dim3((P.frame_count * 4 + 127) / 128), dim3(128), 0, rstream, w.sobol, P.frame_begin, P.frame_count);
         TimedLaunch tl{};
         const bool timed = ws.timed && !STATS;
+        if (seg) {
+            if (d->mode == RT_MODE_CHAP5)
+                hipLaunchKernelGGL(cp_table_kernel, dim3(fold_blocks), dim3(256), 0, rstream, w.cp, d->width, d->height);
+            if (timed) {
+                HIPCHK(hipEventCreate(&tl.a0));
+                HIPCHK(hipEventRecord(tl.a0, rstream));
+            }
+            // one wave per unit (tile x unit_frames frames); it leaves unit_count[unit] and the unit's states for the path loop
+            if (d->mode == RT_MODE_CHAP5)
+                hipLaunchKernelGGL((first_kernel<RT_MODE_CHAP5, STATS>), dim3((unsigned)n_units), dim3(kWave), 0, rstream, P);
+            else if (d->mode == RT_MODE_CHAP4)
+                hipLaunchKernelGGL((first_kernel<RT_MODE_CHAP4, STATS>), dim3((unsigned)n_units), dim3(kWave), 0, rstream, P);
+            else
+                hipLaunchKernelGGL((first_kernel<RT_MODE_CHAP3, STATS>), dim3((unsigned)n_units), dim3(kWave), 0, rstream, P);
+            HIPCHK(hipGetLastError());
+        }
         if (timed) {
             HIPCHK(hipEventCreate(&tl.a));
             HIPCHK(hipEventCreate(&tl.b));
@@ -1436,13 +1631,15 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
 #define LAUNCH2(MODE_, SPILL_)                                                                                  \
     do {                                                                                                        \
         if (entry)                                                                                              \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, SPILL_, true>), dim3(grid), dim3(kWave), 0, rstream, P);  \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, SPILL_, true, false>), dim3(grid), dim3(kWave), 0, rstream, P);  \
         else                                                                                                    \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, SPILL_, false>), dim3(grid), dim3(kWave), 0, rstream, P); \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, SPILL_, false, false>), dim3(grid), dim3(kWave), 0, rstream, P); \
     } while (0)
 #define LAUNCH(MODE_)                  \
     do {                               \
-        if (spill)                     \
+        if (seg)                       \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, false, false, true>), dim3(grid), dim3(kWave), 0, rstream, P); \
+        else if (spill)                \
             LAUNCH2(MODE_, true);      \
         else                           \
             LAUNCH2(MODE_, false);     \
@@ -1489,9 +1686,18 @@ static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count
     int launch_frames = s->tuning.launch_frames;
     if (launch_frames > frame_count) launch_frames = frame_count;
     const size_t per_frame = (size_t)d->width * d->height * 3 * sizeof(float);
-    while (launch_frames > 1 && per_frame * launch_frames > kMaxSampleBytes) launch_frames >>= 1;
     const size_t threads = (size_t)render_blocks(s) * kWave;
     const size_t spill = spill_bytes_needed(s, threads);
+    // two-kernel form (first_kernel -> render_kernel<..., SEG>): every sample slot of a unit may leave a 64-byte path state
+    const bool seg = !s->tuning.single_kernel && !spill && !s->dev.has_entry;
+    const size_t n_tiles = (size_t)((d->width + 7) / 8) * (size_t)((d->height + 7) / 8);
+    const size_t state_per_frame = seg ? n_tiles * kWave * 4 * sizeof(float4) : 0;
+    while (launch_frames > 1 && (per_frame + state_per_frame) * launch_frames > kMaxSampleBytes) launch_frames >>= 1;
+    const int uf = s->tuning.unit_frames;
+    const size_t n_units = n_tiles * (size_t)((launch_frames + uf - 1) / uf);
+    const size_t states_bytes = seg ? n_units * (size_t)uf * kWave * 4 * sizeof(float4) : 0;
+    const size_t count_bytes = seg ? n_units * sizeof(int) : 0;
+    const size_t cp_bytes = seg ? (size_t)d->width * d->height * sizeof(float2) : 0;
     // short launches are dominated by ramp-up and drain (a launch ends with every wave finishing its last paths at falling
     // lane utilisation): those overlap their neighbours.  Long launches stay on the caller's stream, one at a time, so that
     // a kernel's duration means what it says (rt_kernel_time_ms, rocprofv3).
@@ -1515,6 +1721,29 @@ static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count
             HIPCHK(hipMalloc((void**)&sl.d_spill, spill));
             sl.spill_bytes = spill;
         }
+        if (states_bytes > sl.states_bytes || count_bytes > sl.count_bytes || cp_bytes > sl.cp_bytes) {
+            quiesce_slot(sl);
+            if (states_bytes > sl.states_bytes) {
+                (void)hipFree(sl.d_states);
+                sl.d_states = nullptr, sl.states_bytes = 0;
+                if (hipMalloc((void**)&sl.d_states, states_bytes) != hipSuccess)
+                    return set_error(RT_ERR_OOM, "rt_render: cannot allocate the %zu-byte path-state buffer (rt_tuning.single_kernel = 1 renders without it)", states_bytes);
+                sl.states_bytes = states_bytes;
+            }
+            if (count_bytes > sl.count_bytes) {
+                (void)hipFree(sl.d_count);
+                sl.d_count = nullptr, sl.count_bytes = 0;
+                HIPCHK(hipMalloc((void**)&sl.d_count, count_bytes));
+                sl.count_bytes = count_bytes;
+            }
+            if (cp_bytes > sl.cp_bytes) {
+                (void)hipFree(sl.d_cp);
+                sl.d_cp = nullptr, sl.cp_bytes = 0;
+                HIPCHK(hipMalloc((void**)&sl.d_cp, cp_bytes));
+                sl.cp_bytes = cp_bytes;
+            }
+        }
+        ws->slot[k].states = seg ? sl.d_states : nullptr, ws->slot[k].unit_count = sl.d_count, ws->slot[k].cp = sl.d_cp;
         ws->slot[k].queue = sl.d_queue, ws->slot[k].sobol = sl.d_sobol, ws->slot[k].samples = sl.d_samples;
         ws->slot[k].spill = spill ? sl.d_spill : nullptr;
         ws->slot[k].owner = &sl, ws->slot[k].own_stream = pipelined;
@@ -1607,7 +1836,7 @@ int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out) {
 
 int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     if (!s) return set_error(RT_ERR_INVALID_ARG, "rt_scene_set_tuning: NULL scene");
-    const rt_tuning def = {kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames, 0};
+    const rt_tuning def = {kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames, 0, 0};
     rt_tuning n = t ? *t : def;
     if (n.launch_frames <= 0) n.launch_frames = def.launch_frames;
     if (n.unit_frames <= 0) n.unit_frames = def.unit_frames;
@@ -1623,6 +1852,7 @@ int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     s->tuning = n;
     s->dev.cull_eps = n.no_cull ? __builtin_inff() : s->cull_eps;
     n.no_entry_bvh = n.no_entry_bvh > 0 ? 1 : 0;
+    n.single_kernel = n.single_kernel > 0 ? 1 : 0;
     s->tuning = n;
     s->dev.has_entry = (s->has_entry && !n.no_entry_bvh && !n.no_cull) ? 1 : 0;
     return RT_OK;
@@ -1885,27 +2115,29 @@ int rt_primary_hits(rt_scene* s, const rt_render_desc* d, int32_t* tri_host, flo
 int rt_kernel_timing(rt_scene* s, rt_kernel_timing_info* out, int reset) {
     if (!s || !out) return set_error(RT_ERR_INVALID_ARG, "rt_kernel_timing: NULL argument");
     GUARD_DEVICE(s);
-    double total = 0, mx = 0;
-    int n = 0;
+    double total = 0, mx = 0, first = 0;
+    int n = 0, nfirst = 0;
     for (auto& tl : g_launches) {
         float ms = 0;
         if (hipEventSynchronize(tl.b) == hipSuccess && hipEventElapsedTime(&ms, tl.a, tl.b) == hipSuccess) {
             total += ms;
             if (ms > mx) mx = ms;
             ++n;
+            if (tl.a0 && hipEventElapsedTime(&ms, tl.a0, tl.a) == hipSuccess) first += ms, ++nfirst;
         }
     }
     unsigned long long ticks = 0;
     unsigned long long* cell = s->d_clk;
     HIPCHK(hipMemcpy(&ticks, cell, sizeof(ticks), hipMemcpyDeviceToHost));
     out->avg_ms = n ? (float)(total / n) : 0.0f;
+    out->first_avg_ms = nfirst ? (float)(first / nfirst) : 0.0f;
     out->max_ms = (float)mx;
     out->launches = n;
     // the longest-lived wave of the longest launch spans that launch: ticks / duration = the shader clock it ran at
     out->shader_clock_mhz = (mx > 0.0 && ticks) ? (float)((double)ticks / (mx * 1e3)) : 0.0f;
     if (reset) {
         HIPCHK(hipMemset(cell, 0, sizeof(ticks)));
-        for (auto& tl : g_launches) (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
+        for (auto& tl : g_launches) destroy_timed(tl);
         g_launches.clear();
     }
     return RT_OK;
@@ -1950,7 +2182,7 @@ int rt_kernel_time_ms(float* avg_ms, int* launches, int reset) {
     }
 #endif
     if (reset) {
-        for (auto& tl : g_launches) (void)hipEventDestroy(tl.a), (void)hipEventDestroy(tl.b);
+        for (auto& tl : g_launches) destroy_timed(tl);
         g_launches.clear();
     }
     return RT_OK;

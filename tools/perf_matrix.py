@@ -12,6 +12,7 @@ ap.add_argument("--nocull", action="store_true", help="also time every case with
 ap.add_argument("--cache-dir", default="/tmp")
 ap.add_argument("--spp", type=int, default=32)
 ap.add_argument("--launches", type=int, default=5)
+ap.add_argument("--single", action="store_true", help="rt_tuning.single_kernel = 1 (the one-kernel form of the path loop)")
 ap.add_argument("--stats", action="store_true", help="print per-ray traversal means: the reference's walk and the executed walk")
 a = ap.parse_args()
 cases = a.cases.split(",")
@@ -23,7 +24,7 @@ acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
 
 def time_render(sc, d, spp, launches, label):
     for cull in ([True, False] if a.nocull else [True]):
-        sc.set_tuning(no_cull=0 if cull else 1)
+        sc.set_tuning(no_cull=0 if cull else 1, single_kernel=1 if a.single else 0)
         sc.render_device(d, 0, spp, acc.data_ptr(), st)
         torch.cuda.synchronize()
         rt.kernel_time_ms(reset=True)
@@ -32,9 +33,10 @@ def time_render(sc, d, spp, launches, label):
             sc.render_device(d, (i + 1) * spp, spp, acc.data_ptr(), st)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / launches * 1e3
-        ms, n = rt.kernel_time_ms(reset=True)
-        ms *= n / launches  # per render call (a call may be several launches)
-        print(f"{label:34s} cull={'on ' if cull else 'off'} kernel {ms:9.3f} ms  wall {wall:9.3f} ms  {W * H * spp / wall / 1e3:9.1f} Mpaths/s", flush=True)
+        kt = sc.kernel_timing(reset=True)
+        ms = kt.avg_ms * kt.launches / launches  # per render call (a call may be several launches)
+        first = kt.first_avg_ms * kt.launches / launches
+        print(f"{label:34s} cull={'on ' if cull else 'off'} path-loop kernel {ms:9.3f} ms  camera-ray kernel {first:7.3f} ms  wall {wall:9.3f} ms  {W * H * spp / wall / 1e3:9.1f} Mpaths/s", flush=True)
     sc.set_tuning(no_cull=0)
     if a.stats:
         for ex in (False, True):
