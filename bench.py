@@ -301,42 +301,58 @@ def main():
 
     if rank == 0 and renderer is not None:
         kern_ms, launches = timing.avg_ms, timing.launches
+        first_ms = float(getattr(timing, "first_avg_ms", 0.0))  # two-kernel form: the camera-ray kernel that precedes the path loop
         clock = timing.shader_clock_mhz
         key = f"{args.scene}_chap{args.mode}_{W}x{H}_spp{spp}"
         prof = _profile_entry(key)
         if not args.no_stats:
-            # untimed statistics passes over a few frames: (a) the walk the timed kernel EXECUTES (culling, env-visibility
+            # untimed statistics passes over a few frames: (a) the walk the timed kernels EXECUTE (culling, env-visibility
             # rays stop at the first hit) -> the work in `achieved`; (b) the reference's un-culled walk -> SURVEY §8d's
-            # algorithmic fetch pattern, reported beside it
+            # algorithmic fetch pattern, reported beside it; (c) the camera rays' share of (a): the first kernel's work
             fs = min(spp, 4)
             ex = renderer.scene.render_stats(renderer.desc_mean, 0, fs, executed=True)
             rf = renderer.scene.render_stats(renderer.desc_mean, 0, fs)
-            rays = max(ex["rays"], 1)
+            cam = None
+            if first_ms > 0.0:
+                cam = renderer.scene.render_stats_camera(renderer.desc_mean, 0, fs, executed=True)
             rays_per_path = ex["rays"] / max(ex["paths"], 1)
-            I, Lf, T, Hh = (ex[k] / rays for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"))
+            I, Lf, T, Hh = (ex[k] / max(ex["rays"], 1) for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"))
             rI, rLf, rT, rH = (rf[k] / max(rf["rays"], 1) for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"))
             lf = max(1, int(renderer.scene.tuning().launch_frames))  # frames per kernel launch
             paths_per_launch = float(W) * H * min(spp, lf)
             launches_per_step = max(1, (spp + lf - 1) // lf)
-            # §8d flops: 50 per internal node + 90 per triangle test + 40 per closest-hit improvement, + 400 per shaded bounce;
-            # every bounce emits at most one env-visibility and one BRDF ray, so bounces >= (rays - paths) / 2 (a lower bound)
-            bounces_per_path = max(rays_per_path - 1.0, 0.0) / 2.0
-            flops_per_path = (50.0 * I + 90.0 * T + 40.0 * Hh) * rays_per_path + SHADE_FLOPS_PER_BOUNCE * bounces_per_path
-            flops_per_launch = flops_per_path * paths_per_launch
-            tflops = flops_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+            scale = paths_per_launch / max(ex["paths"], 1)  # statistics frames -> one launch
+
+            def walk_flops(st):  # §8d: 50 per internal node + 90 per triangle test + 40 per closest-hit improvement
+                return 50.0 * st["internal_nodes"] + 90.0 * st["triangles_tested"] + 40.0 * st["hit_updates"]
+
+            # every bounce emits at most one env-visibility and one BRDF ray, so bounces >= (rays - paths) / 2 (a lower bound): 400 each
+            bounces = max(ex["rays"] - ex["paths"], 0) / 2.0
+            flops_total = (walk_flops(ex) + SHADE_FLOPS_PER_BOUNCE * bounces) * scale
+            flops_first = walk_flops(cam) * scale if cam else 0.0     # camera rays: traversal only (§8d prices no shading before a bounce)
+            flops_loop = flops_total - flops_first                        # the path-loop kernel: every other ray + all bounce shading
+
+            def tf(fl, ms):
+                return fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+            tflops = tf(flops_loop, kern_ms)
             # bytes: the executed walk on the device layout (64-B node record, 48-B triangle) and the reference's pattern (§8d)
             exec_bytes_per_launch = ((64.0 * I + 48.0 * T) * rays_per_path + 24.0) * paths_per_launch
             ref_bytes_per_launch = ((144.0 * rI + 48.0 * rLf + 72.0 * rT + 72.0 * rH) * rays_per_path) * paths_per_launch + 24.0 * W * H
-            traffic = prof.get("bytes_per_launch")
+            # PMC figures of this workload from the committed profile — only while they still describe the kernel that was timed
+            prof_ms = prof.get("kernel_ms_when_profiled")
+            fresh = bool(prof) and prof_ms and kern_ms > 0 and abs(kern_ms - prof_ms) / prof_ms <= 0.03
+            traffic = prof.get("bytes_per_launch") if fresh else None
             hbm_gbs = (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None
             scene_mb = (renderer.tris.nbytes + renderer.nodes.nbytes) / 1e6
             l2_resident = scene_mb < 32.0
             roof = {
-                "kernel": f"render_kernel<chap{args.mode}>", "kernel_ms": kern_ms, "launches": launches,
+                "kernel": f"render_kernel<chap{args.mode}{', SEG' if first_ms > 0 else ''}>", "kernel_ms": kern_ms, "launches": launches,
                 "traffic": traffic,
+                "profile_head": prof.get("git_head"), "profile_kernel_ms": prof_ms,
                 "shader_clock_mhz": clock,
                 "rays_per_path": rays_per_path, "I": I, "Lf": Lf, "T": T, "H": Hh,
-                "flops_per_launch": flops_per_launch, "valu_tflops": tflops,
+                "flops_per_launch": flops_loop, "valu_tflops": tflops,
                 "valu_frac": tflops / PEAK_VALU_TFLOPS_NO_FMA,
                 "valu_frac_at_measured_clock": (tflops / (PEAK_VALU_TFLOPS_NO_FMA * clock / SPEC_CLOCK_MHZ)) if clock else None,
                 "executed_bytes_per_launch": exec_bytes_per_launch,
@@ -344,7 +360,22 @@ def main():
                 "reference_walk": {"I": rI, "Lf": rLf, "T": rT, "H": rH},
                 "hbm_gbs": hbm_gbs, "hbm_frac": (hbm_gbs / PEAK_HBM_GBS) if hbm_gbs else None,
             }
-            wi = prof.get("valu_wave_instructions_per_launch")
+            if prof and not fresh:
+                roof["profile_note"] = (f"committed PMC profile is of a {prof_ms} ms kernel (head {prof.get('git_head')}); the kernel timed here "
+                                        f"takes {kern_ms:.2f} ms: traffic / issue figures dropped")
+            if first_ms > 0.0 and cam:
+                # the two-kernel form of the path loop: the camera-ray kernel beside the dominant one, and both together (the
+                # figure to hold against earlier rounds' one-kernel roofline)
+                cr = max(cam["rays"], 1)
+                roof["first_kernel"] = {"kernel": f"first_kernel<chap{args.mode}>", "kernel_ms": first_ms, "flops_per_launch": flops_first,
+                                        "valu_tflops": tf(flops_first, first_ms), "frac": tf(flops_first, first_ms) / PEAK_VALU_TFLOPS_NO_FMA,
+                                        "I": cam["internal_nodes"] / cr, "T": cam["triangles_tested"] / cr, "H": cam["hit_updates"] / cr,
+                                        "escaped_fraction": cam["paths"] / cr,
+                                        "traffic": prof.get("first_kernel_bytes_per_launch") if fresh else None}
+                both = tf(flops_total, kern_ms + first_ms)
+                roof["both_kernels"] = {"ms": kern_ms + first_ms, "flops_per_launch": flops_total, "valu_tflops": both,
+                                        "frac": both / PEAK_VALU_TFLOPS_NO_FMA}
+            wi = prof.get("valu_wave_instructions_per_launch") if fresh else None
             if wi and kern_ms > 0 and clock:
                 # issue view: VALU wave-instructions of one launch (PMC SQ_INSTS_VALU, committed profile of this command) x 2
                 # cycles (wave64 on a SIMD-32) / (kernel time x measured clock x 1024 SIMDs)
@@ -355,7 +386,8 @@ def main():
                              "frac": tflops / PEAK_VALU_TFLOPS_NO_FMA,
                              "note": f"scene arrays {scene_mb:.1f} MB are L2-resident: fp32 VALU is the binding resource (no FMA contraction: "
                                      f"peak = 157.3/2 TF). achieved = SURVEY 8d flops of the walk the timed kernel executes "
-                                     f"({launches_per_step} launch(es) per step). HBM side: traffic / kernel time = hbm_gbs"})
+                                     f"({launches_per_step} launch(es) per step; the camera rays' share belongs to first_kernel). "
+                                     f"HBM side: traffic / kernel time = hbm_gbs"})
             else:
                 # a scene far beyond the caches: memory side binds.  achieved = measured traffic when this workload was profiled,
                 # else the executed walk's bytes on the device layout (each record fetched once per visit)

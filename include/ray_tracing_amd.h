@@ -255,6 +255,10 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
  * f5:869).  rays and paths equal rt_render_stats'; the other counters are <= it.  This is the work the timed kernel
  * does (bench.py's roofline numerator); rt_render_stats is the reference's algorithmic count. */
 int rt_render_stats_executed(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out);
+/* The same counters for the camera rays alone (f5:932-940: one hitBVH per sample; `paths` = the samples that end there, i.e.
+ * escape): the share of the walk that the two-kernel form's first kernel does (executed != 0: as executed, else the reference's
+ * walk).  RT_ERR_INVALID_ARG where the scene renders with the one-kernel form (see rt_tuning.single_kernel). */
+int rt_render_stats_camera(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, int executed, rt_trace_stats* out);
 
 /* Average duration (ms) of the path-loop kernel launches made by the calling thread since the last call with
  * reset != 0, measured with HIP events on the launch stream; *launches receives the count. */

@@ -145,6 +145,7 @@ _lib.rt_primary_hits.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, 
 _lib.rt_primary_hits_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
 _lib.rt_render_stats_executed.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
+_lib.rt_render_stats_camera.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_int, C.POINTER(TraceStats)]
 _lib.rt_kernel_timing.argtypes = [C.c_void_p, C.POINTER(KernelTiming), C.c_int]
 _lib.rt_kernel_time_ms.argtypes = [_f32p, C.POINTER(C.c_int), C.c_int]
 _lib.rt_hash_fnv1a64.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
@@ -363,6 +364,12 @@ class Scene:
     def primary_hits_device(self, desc: RenderDesc, tri_ptr: int, dist_ptr: int, stream: int = 0):
         _check(_lib.rt_primary_hits_device(self._h, C.byref(desc), C.c_void_p(tri_ptr), C.c_void_p(dist_ptr),
                                            C.c_void_p(stream)))
+
+    def render_stats_camera(self, desc: RenderDesc, frame_begin: int, frame_count: int, executed: bool = False) -> dict:
+        """The same counters for the camera rays alone (the first kernel of the two-kernel form)."""
+        st = TraceStats()
+        _check(_lib.rt_render_stats_camera(self._h, C.byref(desc), frame_begin, frame_count, 1 if executed else 0, C.byref(st)))
+        return st.as_dict()
 
     def render_stats(self, desc: RenderDesc, frame_begin: int, frame_count: int, executed: bool = False) -> dict:
         """Traversal counters of the reference's walk (default) or of the walk the product kernel executes."""

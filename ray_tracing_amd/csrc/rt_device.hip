@@ -1510,6 +1510,7 @@ struct Workspace {
     int launch_frames = 0;         // frames per kernel launch that `samples` holds
     long long spill_stride = 0;
     bool timed = false;            // bracket the path-loop kernel with HIP events (creates events: allocating callers only)
+    bool camera_only = false;      // statistics of the camera rays alone: stop after first_kernel (two-kernel form only)
 };
 
 static void fill_params(const rt_scene* s, const rt_render_desc* d, RenderParams* P) {
@@ -1597,6 +1598,8 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         P.states = w.states, P.unit_count = w.unit_count, P.cp = w.cp;
         // two-kernel form: where the workspace has room for the path states, the tree fits the LDS stack and no entry BVH is walked
         const bool seg = w.states != nullptr && !spill && !entry;
+        if (ws.camera_only && !seg)
+            return set_error(RT_ERR_INVALID_ARG, "rt_render_stats_camera: this scene renders with the one-kernel path loop (entry BVH, BVH deeper than %d, or rt_tuning.single_kernel): the camera rays are not a kernel of their own", kLdsDepth);
         const bool piped = w.owner && w.own_stream;
         const hipStream_t rstream = piped ? w.owner->stream : stream;
         // the slot's previous user — overlapped or not, on whatever stream — has folded its samples (a wait on an event
@@ -1623,6 +1626,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
                 hipLaunchKernelGGL((first_kernel<RT_MODE_CHAP3, STATS>), dim3((unsigned)n_units), dim3(kWave), 0, rstream, P);
             HIPCHK(hipGetLastError());
         }
+        if (ws.camera_only) continue;
         if (timed) {
             HIPCHK(hipEventCreate(&tl.a));
             HIPCHK(hipEventCreate(&tl.b));
@@ -1975,7 +1979,7 @@ int rt_render(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_c
     return RT_OK;
 }
 
-static int render_stats_impl(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out, int executed) {
+static int render_stats_impl(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out, int executed, bool camera_only = false) {
     if (!out) return set_error(RT_ERR_INVALID_ARG, "rt_render_stats: out is NULL");
     const size_t bytes = (s && d && d->width > 0 && d->height > 0) ? (size_t)d->width * d->height * 3 * sizeof(float) : 0;
     float dummy = 0.0f;
@@ -1992,6 +1996,7 @@ static int render_stats_impl(rt_scene* s, const rt_render_desc* d, int frame_beg
     if (e == hipSuccess && frame_count > 0) {
         Workspace ws;
         rc = scene_workspace(s, d, frame_count, &ws, false);
+        ws.camera_only = camera_only;
         if (rc == RT_OK) rc = launch_render<true>(s, d, frame_begin, frame_count, dev, st, nullptr, ws, executed);
         if (rc == RT_OK) {
             e = hipDeviceSynchronize();
@@ -2061,6 +2066,9 @@ int rt_render_stats(rt_scene* s, const rt_render_desc* d, int frame_begin, int f
 }
 int rt_render_stats_executed(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, rt_trace_stats* out) {
     return render_stats_impl(s, d, frame_begin, frame_count, out, 1);
+}
+int rt_render_stats_camera(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, int executed, rt_trace_stats* out) {
+    return render_stats_impl(s, d, frame_begin, frame_count, out, executed ? 1 : 0, true);
 }
 
 int rt_primary_hits_device(rt_scene* s, const rt_render_desc* d, int32_t* tri_dev, float* dist_dev, void* stream) {

@@ -979,6 +979,40 @@ def test_full_size_kernel_vs_libm_oracle_statistical(request, hdr_pair, mode, sc
     assert rmse <= 0.02 and rel <= 0.01
 
 
+@pytest.mark.parametrize("mode", [3, 4, 5])
+def test_one_kernel_and_two_kernel_forms_of_the_path_loop_agree(scene_small, hdr_pair, mode):
+    """Default: the camera rays of a launch are traced by first_kernel (one lane per pixel), which leaves path states for the
+    wave-scheduled path loop; rt_tuning.single_kernel = 1: everything in the path loop, as the entry-BVH / deep-tree scenes and
+    the no-allocation entry point run.  Same images, same statistics (reference walk and executed walk), both equal the oracle's;
+    the camera rays' own counters are a consistent share of them."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(-25.0, 18.0, 3.1)
+    W, H, F = 141, 77, 5  # ragged tiles
+    d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam)
+    ref, ost = O.render(tris, nodes, hdr, cache, W, H, mode, eye, cam, 2, F)
+    two = sc.render(d, 2, F)
+    st2, ex2 = sc.render_stats(d, 2, F), sc.render_stats(d, 2, F, executed=True)
+    camst, camex = sc.render_stats_camera(d, 2, F), sc.render_stats_camera(d, 2, F, executed=True)
+    sc.set_tuning(single_kernel=1)
+    one = sc.render(d, 2, F)
+    st1, ex1 = sc.render_stats(d, 2, F), sc.render_stats(d, 2, F, executed=True)
+    _assert_images_equal(two, ref, f"two-kernel form, mode {mode}")
+    _assert_images_equal(one, ref, f"one-kernel form, mode {mode}")
+    assert st2 == ost and st1 == ost
+    # (an env-visibility ray stops at its first hit; how many triangles of that last leaf a cooperative leaf pass had taken up
+    # by then depends on the other lanes of the wave, so the executed triangle counters of chapter 5 vary by a few per million)
+    for k in ex1:
+        assert ex1[k] == ex2[k] or (mode == 5 and k in ("triangles_tested", "hit_updates") and abs(ex1[k] - ex2[k]) <= 1e-3 * ex1[k]), k
+    assert camst["rays"] == W * H * F == camex["rays"]  # one camera ray per sample
+    assert 0 < camst["paths"] < W * H * F and camst["paths"] == camex["paths"]  # the samples that escape at once
+    for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"):
+        assert 0 < camex[k] <= camst[k] < ost[k] and camex[k] < ex2[k]
+    with pytest.raises(rt.RtError):
+        sc.render_stats_camera(d, 2, F)  # one-kernel form: the camera rays are not a kernel of their own
+
+
 def test_render_multi_replicas_in_one_process(scene_small, hdr_pair):
     """rt_render_multi: three replicas of the scene (here all on the box's one GPU; one per device in production) render disjoint
     frame ranges concurrently and their SUM buffers are added in replica order: two steps of it equal the oracle's sums added in

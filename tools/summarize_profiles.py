@@ -35,10 +35,11 @@ def first_db(d):
     return dbs[0] if dbs else None
 
 
-def traffic_entry(pmc, prefix=""):
-    """bytes per launch etc. of the LAST render_kernel dispatch of each pass (the timed launch of a --steps 1 --warmup 1 run)."""
-    def last(name):
-        v = pmc.get(prefix + name)
+def traffic_entry(pmc, prefix="", stats=None, head=None):
+    """bytes per launch etc. of the LAST render_kernel dispatch of each pass (the timed launch of a --steps 1 --warmup 1 run);
+    the same for first_kernel (two-kernel form of the path loop) under first_kernel_*."""
+    def last(name, first=False):
+        v = pmc.get(prefix + name + (":first" if first else ""))
         return v[-1] if v else {}
     f, w, q = last("pmc_fetch"), last("pmc_write"), last("pmc_sq")
     if not f or not w:
@@ -58,6 +59,22 @@ def traffic_entry(pmc, prefix=""):
         if q.get("SQ_WAVE_CYCLES"):
             e["wave_wait_fraction"] = q.get("SQ_WAIT_ANY", 0.0) / q["SQ_WAVE_CYCLES"]
         e["grbm_gui_active_cycles_sum"] = q.get("GRBM_GUI_ACTIVE")
+    f1, w1, q1 = last("pmc_fetch", True), last("pmc_write", True), last("pmc_sq", True)
+    if f1 and w1:
+        e["first_kernel_bytes_per_launch"] = int((2.0 * f1.get("FETCH_SIZE", 0.0) + w1.get("WRITE_SIZE", 0.0)) * 1024)
+    if q1.get("SQ_INSTS_VALU"):
+        e["first_kernel_valu_wave_instructions_per_launch"] = int(q1["SQ_INSTS_VALU"])
+        if q1.get("SQ_ACTIVE_INST_VALU"):
+            e["first_kernel_valu_lane_util"] = q1.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * q1["SQ_ACTIVE_INST_VALU"])
+        if q1.get("SQ_WAVE_CYCLES"):
+            e["first_kernel_wave_wait_fraction"] = q1.get("SQ_WAIT_ANY", 0.0) / q1["SQ_WAVE_CYCLES"]
+    # what the figures belong to: bench.py drops them when the kernel it times is no longer this one (> 3 % off)
+    for r in stats or []:
+        if "render_kernel" in r["kernel"] and "kernel_ms_when_profiled" not in e:
+            e["kernel_ms_when_profiled"] = r["avg_us"] / 1e3
+        if "first_kernel" in r["kernel"] and "first_kernel_ms_when_profiled" not in e:
+            e["first_kernel_ms_when_profiled"] = r["avg_us"] / 1e3
+    e["git_head"] = head
     return e
 
 
@@ -79,11 +96,18 @@ def bench_key(logpath):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    head = None
+    try:  # written before the gpurun call (the box has no .git): git rev-parse --short HEAD > .git_head
+        head = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".git_head")).read().strip() or None
+    except OSError:
+        pass
+    all_stats = {}
     for sub, suffix in (("stats", ""), ("syn_stats", "_synthetic")):
         db = first_db(os.path.join(src, sub))
         if not db:
             continue
         stats = kernel_stats(db)
+        all_stats["syn_" if suffix else ""] = stats
         with open(dst + suffix + "_kernel_stats.csv", "w") as f:
             f.write("kernel,calls,total_us,avg_us,percent\n")
             for r in stats:
@@ -95,6 +119,9 @@ def main():
             db = first_db(d)
             if db:
                 pmc[os.path.basename(d)] = counters(db)
+                first = counters(db, "first_kernel")
+                if first:
+                    pmc[os.path.basename(d) + ":first"] = first
     with open(dst + "_pmc.json", "w") as f:
         json.dump(pmc, f, indent=1)
     for name in ("bench.json.log", "bench_under_rocprof.log", "pytest_gpu.log", "baselines.log", "syn_bench.json.log", "syn_bench_under_rocprof.log"):
@@ -109,7 +136,7 @@ def main():
         table = {}
     for prefix, log in (("", "pmc_sq.log"), ("syn_", "syn_pmc_sq.log")):
         key, _ = bench_key(os.path.join(src, log))
-        e = traffic_entry(pmc, prefix)
+        e = traffic_entry(pmc, prefix, all_stats.get(prefix), head)
         if key and e:
             e["source"] = os.path.basename(dst) + "_pmc.json"
             table[key] = e
