@@ -93,7 +93,7 @@ def launch_ranks(args):
 class GpuRenderer:
     """The product path: one replicated scene per rank, rt_render_device into device buffers."""
 
-    def __init__(self, args, local_rank, multi):
+    def __init__(self, args, local_rank, multi, rank=0, world=1):
         import torch
 
         import ray_tracing_amd as rt
@@ -106,7 +106,8 @@ class GpuRenderer:
         elif args.scene == "small":
             tris, nodes = scenes.small_scene()
         else:
-            tris, nodes = scenes.synthetic_scene_cached(args.cache_dir, args.synthetic_objects, args.synthetic_subdiv)
+            # N > 1: rank 0 builds (or loads) and saves, the others wait for the cache file and load it — before any GPU call
+            tris, nodes = scenes.synthetic_scene_cached(args.cache_dir, args.synthetic_objects, args.synthetic_subdiv, rank=rank, world=world)
         self.tris, self.nodes = tris, nodes
         self.hdr, self.cache = scenes.hdr_and_cache()
         self.scene = rt.Scene(tris, nodes, self.hdr, self.cache, device=local_rank)
@@ -176,7 +177,7 @@ def main():
             if "RANK" not in os.environ:  # RT_BENCH_FORCE_DIST without a launcher: a one-rank group on this process
                 os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "RANK": "0", "WORLD_SIZE": "1"})
             dist.init_process_group(backend="nccl", device_id=dev)
-        renderer = GpuRenderer(args, local_rank, multi)
+        renderer = GpuRenderer(args, local_rank, multi, rank, world)
         rt = renderer.rt
         W, H, spp = args.width, args.height, args.spp
         # N = 1: one accumulation buffer (the running mean).  N > 1: two sum buffers, so that the RCCL reduce of step s (on its

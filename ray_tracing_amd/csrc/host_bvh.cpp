@@ -228,9 +228,21 @@ struct Builder {
         // prefix / suffix boxes of the sweep (c5:509-541) in this thread's scratch: no task scheduling point until they are
         // dead, so the buffer cannot be taken over by another node in between.  The reference fills them with -INF / INF and
         // folds in place; the running values below are the same recurrence with those initial values.
+        // (the per-thread buffer only serves nodes up to kScratchTris triangles — 3 MB per worker thread, kept for the life
+        // of the process; a larger node that ends up here, e.g. the root of a scene with a non-finite centroid, which cannot take
+        // the all-threads path, gets a buffer of its own that is released when the node is done)
+        constexpr size_t kScratchTris = 65536;
         static thread_local std::vector<vec3> scratch;
-        if (scratch.size() < 4 * (size_t)cnt) scratch.resize(4 * (size_t)cnt);
-        vec3* const leftMax = scratch.data();
+        std::unique_ptr<vec3[]> big;
+        vec3* base;
+        if ((size_t)cnt <= kScratchTris) {
+            if (scratch.size() < 4 * (size_t)cnt) scratch.resize(4 * (size_t)cnt);
+            base = scratch.data();
+        } else {
+            big.reset(new vec3[4 * (size_t)cnt]);
+            base = big.get();
+        }
+        vec3* const leftMax = base;
         vec3* const leftMin = leftMax + cnt;
         vec3* const rightMax = leftMin + cnt;
         vec3* const rightMin = rightMax + cnt;

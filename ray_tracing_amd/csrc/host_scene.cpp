@@ -15,6 +15,14 @@
 
 namespace rta {
 
+// dst[i] += src[i] on all host cores (rt_render_multi's reduce: one call per replica, in replica order, so every element sees
+// the additions in that order)
+void add_into(float* dst, const float* src, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) dst[i] += src[i];
+}
+
+
 static thread_local char g_err[512] = "";
 
 int set_error(int code, const char* fmt, ...) {

@@ -1306,6 +1306,8 @@ struct rt_scene {
     unsigned long long* d_clk = nullptr;  // longest wave lifetime (ticks) since the last rt_kernel_timing reset
     float* d_frame = nullptr;    // rt_render: device copy of the caller's host accumulation buffer
     size_t frame_bytes = 0;
+    float* h_stage = nullptr;    // rt_render_multi: pinned host staging of this replica's sum buffer
+    size_t stage_bytes = 0;
     int cu_count = 0;
     rt_tuning tuning{kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames, 0, 0};
     float cull_eps = 0.0f;       // scene part of the culling margin; +inf = the BVH / triangles do not allow culling
@@ -1335,6 +1337,7 @@ void rt_scene_destroy(rt_scene* s) {
     DeviceGuard guard(s->device);
     (void)hipDeviceSynchronize();  // launches may still be in flight on the internal streams
     (void)hipFree(s->d_frame);
+    if (s->h_stage) (void)hipHostFree(s->h_stage);
     (void)hipFree(s->d_ttri), (void)hipFree(s->d_dmat), (void)hipFree(s->d_tris), (void)hipFree(s->d_nodes), (void)hipFree(s->d_hdr);
     (void)hipFree(s->d_cdir), (void)hipFree(s->d_spill), (void)hipFree(s->d_clk);
     (void)hipFree(s->d_nodes2), (void)hipFree(s->d_ttri2), (void)hipFree(s->d_map2), (void)hipFree(s->d_leafx), (void)hipFree(s->d_parentx);
@@ -2047,16 +2050,22 @@ int rt_render_multi(rt_scene* const* scenes, int n_scenes, const rt_render_desc*
             HIPCHK(hipMalloc((void**)&s->d_frame, bytes));
             s->frame_bytes = bytes;
         }
+        if (bytes > s->stage_bytes) {  // pinned staging kept with the replica: the download is asynchronous and at link rate
+            if (s->h_stage) (void)hipHostFree(s->h_stage);
+            s->h_stage = nullptr, s->stage_bytes = 0;
+            HIPCHK(hipHostMalloc((void**)&s->h_stage, bytes, hipHostMallocDefault));
+            s->stage_bytes = bytes;
+        }
         HIPCHK(hipMemsetAsync(s->d_frame, 0, bytes, nullptr));
         const int rc = rt_render_device(s, &ds, frame_begin + k * frames_each, frames_each, s->d_frame, nullptr);
         if (rc != RT_OK) return rc;
+        HIPCHK(hipMemcpyAsync(s->h_stage, s->d_frame, bytes, hipMemcpyDeviceToHost, nullptr));  // behind the fold, on the same stream
     }
-    std::vector<float> stage(n);
-    for (int k = 0; k < n_scenes; ++k) {  // the "reduce": in scene order
+    for (int k = 0; k < n_scenes; ++k) {  // the "reduce": in scene order (per pixel the same fp32 additions in the same order as a scalar loop)
         rt_scene* s = scenes[k];
         GUARD_DEVICE(s);
-        HIPCHK(hipMemcpy(stage.data(), s->d_frame, bytes, hipMemcpyDeviceToHost));  // (synchronises with the default stream)
-        for (size_t i = 0; i < n; ++i) sum_host[i] += stage[i];
+        HIPCHK(hipStreamSynchronize(nullptr));
+        add_into(sum_host, s->h_stage, n);  // all host cores (host_scene.cpp)
     }
     return RT_OK;
 }

@@ -29,6 +29,7 @@ struct NodeRec {
 static_assert(sizeof(NodeRec) == 48, "BVHNode_encoded is 48 bytes");
 
 int set_error(int code, const char* fmt, ...);
+void add_into(float* dst, const float* src, size_t n);  // dst[i] += src[i], all host cores (host_scene.cpp)
 
 // host_fastbvh.cpp: the device-private entry BVH (binned SAH) over the same triangles; never visible at the ABI
 struct FastBvhNode {

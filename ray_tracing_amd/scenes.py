@@ -115,22 +115,51 @@ def synthetic_scene(n_objects: int = 64, subdiv: int = 32, seed: int = 0x5EED):
 def cached_build(path: str, key: int, builder):
     """SURVEY 8f-1: ``builder()`` -> (triangles, nodes) runs only when ``path`` is missing, stale (other ``key``) or corrupt;
     otherwise the arrays come from the cache file (the reference's own layouts, raw fp32).  ``key`` = hash of the inputs,
-    e.g. ``rt.hash_fnv1a64(open(obj, 'rb').read(), rt.hash_fnv1a64(params_bytes))``."""
+    e.g. ``rt.hash_fnv1a64(open(obj, 'rb').read(), rt.hash_fnv1a64(params_bytes))``.  The file appears atomically (written
+    beside ``path``, then renamed), so a concurrent reader sees either no file or a complete one."""
     from . import RtError, scene_cache_load, scene_cache_save
     try:
         return scene_cache_load(path, key)
     except RtError:
         tris, nodes = builder()
+        tmp = f"{path}.tmp.{os.getpid()}"
         try:
-            scene_cache_save(path, key, tris, nodes)
-        except RtError:
-            pass  # a cache that cannot be written (read-only directory, another rank's race) is not fatal: the arrays are valid
+            scene_cache_save(tmp, key, tris, nodes)
+            os.replace(tmp, path)
+        except (RtError, OSError):
+            # a cache that cannot be written (read-only directory) is not fatal: the arrays are valid
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
         return tris, nodes
 
 
-def synthetic_scene_cached(cache_dir: str, n_objects: int = 64, subdiv: int = 32, seed: int = 0x5EED):
-    """synthetic_scene behind the on-disk cache: the 10 M-triangle build (8 s on 16 cores, 2.5 s of it numpy) is paid once."""
+def shared_build(path: str, key: int, builder, rank: int, world: int, wait_s: float = 1800.0, poll_s: float = 0.2):
+    """One build per node for a multi-process job (one process per GPU, bench.py --gpus N): rank 0 loads or builds-and-saves the
+    scene (``cached_build``); every other rank waits for the cache file and loads it — N concurrent SAH builds of a 10 M-triangle
+    scene would take N times the memory and, at 16 / N threads each, several times as long.  Runs before anything touches the
+    GPU.  A rank that waits longer than ``wait_s`` (rank 0 died, unwritable directory) builds the scene itself."""
+    import time
+
+    from . import RtError, scene_cache_load
+    if world <= 1 or rank == 0:
+        return cached_build(path, key, builder)
+    deadline = time.monotonic() + wait_s
+    while time.monotonic() < deadline:
+        if os.path.exists(path):
+            try:
+                return scene_cache_load(path, key)
+            except RtError:
+                pass  # a stale file of an earlier run (other key): rank 0 is about to replace it
+        time.sleep(poll_s)
+    return cached_build(path, key, builder)
+
+
+def synthetic_scene_cached(cache_dir: str, n_objects: int = 64, subdiv: int = 32, seed: int = 0x5EED, rank: int = 0, world: int = 1):
+    """synthetic_scene behind the on-disk cache: the 10 M-triangle build (8 s on 16 cores, 2.5 s of it numpy) is paid once —
+    per node, by rank 0, when ``world`` > 1 (``shared_build``)."""
     from . import hash_fnv1a64
     key = hash_fnv1a64(np.array([n_objects, subdiv, seed, 8], np.int64), hash_fnv1a64(open(_m("quad.obj"), "rb").read()))
     path = os.path.join(cache_dir, f"synthetic_{n_objects}_{subdiv}_{seed:x}.rtsc")
-    return cached_build(path, key, lambda: synthetic_scene(n_objects, subdiv, seed))
+    return shared_build(path, key, lambda: synthetic_scene(n_objects, subdiv, seed), rank, world)

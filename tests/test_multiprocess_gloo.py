@@ -93,3 +93,44 @@ def test_bench_launches_its_own_ranks_and_verifies(tmp_path):
     assert out["n_gpus"] == 2 and out["world_size_seen"] == 2 and out["scaling"] == "weak"
     assert out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
     assert out["verify"]["ok"] and out["verify"]["frames"] == 2 * 2 * 2
+
+
+def _shared_worker(rank, world, path, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import time
+
+    from ray_tracing_amd import scenes
+    built = []
+
+    def builder():
+        built.append(rank)
+        if rank == 0:
+            time.sleep(1.0)  # the other rank is already polling for the file by now
+        return scenes.synthetic_scene(3, 6)
+
+    tris, nodes = scenes.shared_build(path, 0x5EED0001, builder, rank, world, wait_s=120.0, poll_s=0.05)
+    np.save(os.path.join(outdir, f"tris{rank}.npy"), tris)
+    np.save(os.path.join(outdir, f"nodes{rank}.npy"), nodes)
+    with open(os.path.join(outdir, f"built{rank}.txt"), "w") as f:
+        f.write(str(len(built)))
+
+
+def test_one_scene_build_per_node_rank0_builds_the_others_load(tmp_path):
+    """bench.py --gpus N (one process per GPU): rank 0 builds the scene and saves it to the on-disk cache, every other rank waits
+    for the file and loads it (scenes.shared_build) — here with two processes and a stale cache file of another key in place."""
+    import torch.multiprocessing as mp
+
+    path = str(tmp_path / "scene.rtsc")
+    sys.path.insert(0, ROOT)
+    import ray_tracing_amd as rt
+    from ray_tracing_amd import scenes
+    t0, n0 = scenes.small_scene()
+    rt.scene_cache_save(path, 0x0BADBEEF, t0, n0)  # left over by an earlier run: must not be picked up
+    mp.spawn(_shared_worker, args=(2, path, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "built0.txt").read_text() == "1" and (tmp_path / "built1.txt").read_text() == "0"
+    want_t, want_n = scenes.synthetic_scene(3, 6)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"tris{r}.npy").view(np.uint32), want_t.view(np.uint32))
+        assert np.array_equal(np.load(tmp_path / f"nodes{r}.npy")[1:].view(np.uint32), want_n[1:].view(np.uint32))
+    assert not [p for p in os.listdir(tmp_path) if ".tmp." in p]  # the temporary file was renamed into place
