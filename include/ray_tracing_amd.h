@@ -84,6 +84,12 @@ int rt_hdr_load(const char* path, int* width, int* height, float** rgb);
 /* calculateHdrCache, c5:595-698: W*H*3 floats (x/W, y/H, pdf) from marginal/conditional CDF inversion. */
 int rt_hdr_cache(const float* rgb, int width, int height, float* cache_out);
 
+/* The same table computed on the GPU (current HIP device), bit-identical to rt_hdr_cache: calculateHdrCache, c5:595-698 — the
+ * fp32 running sum lumSum in the reference's row-major order (c5:602-611) by one wave, the marginal / conditional prefix sums
+ * (c5:622-651) by one lane per column, the per-texel std::lower_bound searches (c5:665-682) in parallel.  SURVEY 8(f)4; the BVH
+ * build stays on the host ("Start-up").  Host pointers in and out; RT_ERR_NO_DEVICE without a GPU. */
+int rt_hdr_cache_gpu(const float* rgb, int width, int height, float* cache_out);
+
 /* Orbit camera of display(), c5:716-720: eye = r*(-sin(rot)cos(up), sin(up), cos(rot)cos(up)),
  * cameraRotate = inverse(lookAt(eye, 0, +Y)), column-major. */
 int rt_camera(float rotat_angle_deg, float up_angle_deg, float r, float eye[3], float camera_rotate16[16]);

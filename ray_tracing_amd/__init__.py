@@ -124,6 +124,7 @@ _lib.rt_mesh_read_obj_chap2.argtypes = [C.c_void_p, C.c_char_p, C.c_float, C.c_f
 _lib.rt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(_f32p), C.POINTER(C.c_int)]
 _lib.rt_hdr_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_f32p)]
 _lib.rt_hdr_cache.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+_lib.rt_hdr_cache_gpu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 _lib.rt_camera.argtypes = [C.c_float, C.c_float, C.c_float, _f32p, _f32p]
 _lib.rt_tonemap_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
 _lib.rt_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -241,6 +242,14 @@ def calculateHdrCache(hdr: np.ndarray) -> np.ndarray:
     hdr = np.ascontiguousarray(hdr, dtype=np.float32)
     out = np.empty_like(hdr)
     _check(_lib.rt_hdr_cache(hdr.ctypes.data, hdr.shape[1], hdr.shape[0], out.ctypes.data))
+    return out
+
+
+def calculateHdrCacheGpu(hdr: np.ndarray) -> np.ndarray:
+    """calculateHdrCache, c5:595-698, on the GPU (rt_hdr_cache_gpu): bit-identical to calculateHdrCache."""
+    hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+    out = np.empty_like(hdr)
+    _check(_lib.rt_hdr_cache_gpu(hdr.ctypes.data, hdr.shape[1], hdr.shape[0], out.ctypes.data))
     return out
 
 

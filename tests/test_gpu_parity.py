@@ -1013,6 +1013,29 @@ def test_one_kernel_and_two_kernel_forms_of_the_path_loop_agree(scene_small, hdr
         sc.render_stats_camera(d, 2, F)  # one-kernel form: the camera rays are not a kernel of their own
 
 
+def test_hdr_cache_on_the_gpu_equals_the_host_table(hdr_pair):
+    """calculateHdrCache (c5:595-698) on the GPU — rt_hdr_cache_gpu — against the oracle's table and the host
+    entry point, to the bit: the bundled 1024x512 map (cache[23] = 5.94006e-07), a random 64x32 map, a ragged 37x19 map
+    and a map with an all-black column and an all-black tail (0 / 0 = NaN in the conditional CDF: the bisection of
+    std::lower_bound decides what comes out, and it is restated step for step)."""
+    hdr, cache = hdr_pair
+    rng = np.random.RandomState(5)
+    maps = [hdr, (rng.rand(32, 64, 3) ** 4 * 20).astype(np.float32), rng.rand(19, 37, 3).astype(np.float32)]
+    black = (rng.rand(24, 48, 3) * 3).astype(np.float32)
+    black[:, 7, :] = 0.0
+    black[:, 40:, :] = 0.0
+    maps.append(black)
+    for m in maps:
+        want = O.hdr_cache(m)
+        got = rt.calculateHdrCacheGpu(m)
+        host = rt.calculateHdrCache(m)
+        same = (_bits(got) == _bits(want)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), f"{m.shape}: {int((~same).sum())} of {same.size} floats differ from the oracle"
+        assert ((_bits(host) == _bits(got)) | (np.isnan(host) & np.isnan(got))).all()
+    assert np.float32(rt.calculateHdrCacheGpu(hdr).reshape(-1)[23]) == np.float32(cache.reshape(-1)[23])
+    assert abs(float(cache.reshape(-1)[23]) - 5.94006e-07) < 1e-12
+
+
 def test_render_multi_replicas_in_one_process(scene_small, hdr_pair):
     """rt_render_multi: three replicas of the scene (here all on the box's one GPU; one per device in production) render disjoint
     frame ranges concurrently and their SUM buffers are added in replica order: two steps of it equal the oracle's sums added in
