@@ -348,7 +348,7 @@ def main():
             scene_mb = (renderer.tris.nbytes + renderer.nodes.nbytes) / 1e6
             l2_resident = scene_mb < 32.0
             roof = {
-                "kernel": f"render_kernel<chap{args.mode}{', SEG' if first_ms > 0 else ''}>", "kernel_ms": kern_ms, "launches": launches,
+                "kernel": f"render_kernel<chap{args.mode}{', SEG' if first_ms > 0 else ''}>", "kernel_ms": kern_ms, "kernel_ms_max": float(timing.max_ms), "launches": launches,
                 "traffic": traffic,
                 "profile_head": prof.get("git_head"), "profile_kernel_ms": prof_ms,
                 "shader_clock_mhz": clock,

@@ -241,6 +241,108 @@ __device__ __forceinline__ int hitBVH(const DevScene& sc, const LaneStack& stk, 
 }
 
 
+// ---- hitBVH for a closest-hit ray on a scene with an entry BVH, one lane per ray (first_kernel) -----------------------------
+// The three phases of render_kernel's ENTRY instantiations (see there and DESIGN.md section 5, "The entry BVH"), as a plain loop:
+//   0: walk the 4-wide entry BVH with the conservative box test and the real hitTriangle -> W, the closest acceptable triangle
+//      (none: the reference misses too), and whether another triangle shares its distance exactly;
+//   1: no tie: check, with the reference's own hitAABB, the boxes from W's reference leaf upwards (only the levels that need it,
+//      `leafx` bits 24..31): all pass => the reference returns W at t_W;
+//   2: a tie, a refuted check or a ray that must not be culled: the reference's own (culled) walk, hitBVH above.
+// Statistics builds count what is executed (they come here only for rt_render_stats_executed).
+template <bool STATS, bool SPILL>
+__device__ __forceinline__ int hitBVH_entry(const DevScene& sc, const LaneStack& stk, vec3 S, vec3 d, float* dist, Stats& st) {
+    const vec3 invdir = v3(1.0f) / d;
+    const bool slow = !(finite3(invdir) && finite3(S));
+    const float ceps = cull_margin(sc.cull_eps, sc.cull_geo_max, S, invdir, slow);
+    if (!(ceps < __builtin_inff())) return hitBVH<false, TIE_SHADER, STATS, SPILL>(sc, stk, S, d, dist, st, true);
+    if (STATS) st.rays++;
+    float best = INF_;
+    int best_tri = -1;
+    bool tie = false;
+    int sp = 0;
+    int cur = sc.root_entry2;
+    while (true) {
+        if (cur >= 0) {
+            if (STATS) st.internal++;
+            const float4* nb = sc.nodes2 + (size_t)cur * 8;
+            const float4 q0 = nb[0], q1 = nb[1], q2 = nb[2], q3 = nb[3], q4 = nb[4], q5 = nb[5], q6 = nb[6], q7 = nb[7];
+            float c1, c2, c3, c4, e1, e2, e3, e4;
+            (void)hitAABB_cull(S, invdir, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), ceps, q3.z, &c1, &e1);
+            (void)hitAABB_cull(S, invdir, v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), ceps, q3.w, &c2, &e2);
+            (void)hitAABB_cull(S, invdir, v3(q4.x, q4.y, q4.z), v3(q4.w, q5.x, q5.y), ceps, q7.z, &c3, &e3);
+            (void)hitAABB_cull(S, invdir, v3(q5.z, q5.w, q6.x), v3(q6.y, q6.z, q6.w), ceps, q7.w, &c4, &e4);
+            int n0 = __float_as_int(q3.x), n1 = __float_as_int(q3.y), n2 = __float_as_int(q7.x), n3 = __float_as_int(q7.y);
+            float k0 = (c1 <= e1 && e1 >= 0.0f && c1 <= best) ? __builtin_fmaxf(c1, 1e-30f) : INF_;  // (children 0 and 1 always exist)
+            float k1 = (c2 <= e2 && e2 >= 0.0f && c2 <= best) ? __builtin_fmaxf(c2, 1e-30f) : INF_;
+            float k2 = (c3 <= e3 && e3 >= 0.0f && c3 <= best && n2 != kNoChild) ? __builtin_fmaxf(c3, 1e-30f) : INF_;
+            float k3 = (c4 <= e4 && e4 >= 0.0f && c4 <= best && n3 != kNoChild) ? __builtin_fmaxf(c4, 1e-30f) : INF_;
+#define RT_CSWAP(ka, kb, na, nb_)                    \
+    {                                                \
+        const bool sw_ = kb < ka;                    \
+        const float tk_ = sw_ ? kb : ka;             \
+        kb = sw_ ? ka : kb, ka = tk_;                \
+        const int tn_ = sw_ ? nb_ : na;              \
+        nb_ = sw_ ? na : nb_, na = tn_;              \
+    }
+            RT_CSWAP(k0, k1, n0, n1) RT_CSWAP(k2, k3, n2, n3) RT_CSWAP(k0, k2, n0, n2) RT_CSWAP(k1, k3, n1, n3) RT_CSWAP(k1, k2, n1, n2)
+#undef RT_CSWAP
+            if (k3 < INF_) stack_push<SPILL>(stk, sp++, n3);
+            if (k2 < INF_) stack_push<SPILL>(stk, sp++, n2);
+            if (k1 < INF_) stack_push<SPILL>(stk, sp++, n1);
+            if (k0 < INF_) {
+                cur = n0;
+                continue;
+            }
+        } else {
+            if (STATS) st.leaves++;
+            const int first = cur & 0x00ffffff, n = ((cur >> 24) & 0x7f) + 1;
+            float leaf_best = INF_;
+            for (int i = first; i < first + n; ++i) {
+                const float4 a = sc.ttri2[i * 3 + 0], b = sc.ttri2[i * 3 + 1], c = sc.ttri2[i * 3 + 2];
+                float t;
+                if (STATS) st.tris++;
+                if (hitTriangleT(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), S, d, &t)) {
+                    if (STATS && t < leaf_best) st.updates++, leaf_best = t;
+                    if (t == best && i != best_tri) tie = true;  // a tie the entry BVH's order must not decide
+                    if (t < best) best = t, best_tri = i, tie = false;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack_pop<SPILL>(stk, --sp);
+    }
+    if (best_tri < 0) {  // nothing acceptable on this ray: the reference misses too
+        *dist = INF_;
+        return -1;
+    }
+    if (!tie) {
+        const int w = sc.map2[best_tri];
+        const unsigned lx = sc.leafx[w];
+        int steps = (ceps <= sc.climb_eps) ? (int)(lx >> 24) : 255;
+        bool verified = steps == 0;
+        int x = (int)(lx & 0x00ffffffu);
+        while (!verified) {
+            if (STATS) st.internal++;
+            const int rec = x >> 1;
+            const float4* nb = sc.nodes + (size_t)rec * 4;
+            const float4 q0 = nb[0], q1 = nb[1], q2 = nb[2], q3 = nb[3];
+            const int up = sc.parentx[rec];
+            float c;
+            const float dv = (x & 1) ? hitAABB_cull(S, invdir, v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), ceps, q3.w, &c)
+                                     : hitAABB_cull(S, invdir, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), ceps, q3.z, &c);
+            if (!(dv > 0.0f)) break;  // refuted: the reference never reaches W's leaf
+            if (steps != 255) --steps;
+            if (up < 0 || steps == 0) verified = true; else x = up;
+        }
+        if (verified) {
+            *dist = best;
+            return w;
+        }
+    }
+    if (STATS) st.rays--;  // (hitBVH counts the ray again)
+    return hitBVH<false, TIE_SHADER, STATS, SPILL>(sc, stk, S, d, dist, st, true);
+}
+
 // ---- rest of hitTriangle for the closest hit only (f5:205-219; f4/f3:393-406) ----------------------------------
 struct Hit {
     vec3 hitPoint, normal, viewDir;
@@ -1080,26 +1182,31 @@ __global__ void __launch_bounds__(256) cp_table_kernel(float2* out, int width, i
 //            direction.  The state {hitPoint, next direction, N, V, seed, pixel, frame | kind, triangle} goes to the unit's
 //            region of `states`, packed from its start (ballot + mbcnt); unit_count[unit] = how many.
 // render_kernel<..., SEG> continues from those states.  Per sample the arithmetic and the RNG call order are unchanged.
-template <int MODE, bool STATS>
-__global__ void __launch_bounds__(kWave) first_kernel(const RenderParams P) {
+// Launch shape: one wave per unit where the tree fits the LDS part of the stack (hardware dispatch balances the load best:
+// persistent waves with a static stride were measured 25 % slower on config 5); deep trees (SPILL) bound the global spill buffer
+// with persistent waves — as many as the path loop uses — that take their next unit from a counter.  ENTRY: hitBVH_entry.
+template <int MODE, bool STATS, bool SPILL, bool ENTRY>
+__global__ void __launch_bounds__(kWave) first_kernel(const RenderParams P, int n_units) {
     __shared__ int s_stack[kLdsDepth * kWave];
     const DevScene& sc = P.sc;
     const int lane = threadIdx.x;
     const int tilesx = (P.width + 7) >> 3, n_tiles = tilesx * ((P.height + 7) >> 3);
-    const int tile = (int)(blockIdx.x % (unsigned)n_tiles), group = (int)(blockIdx.x / (unsigned)n_tiles);
+    LaneStack stk;
+    stk.lds = &s_stack[lane], stk.lstride = kWave;
+    stk.spill = SPILL ? (P.spill + ((long long)blockIdx.x * kWave + lane)) : nullptr, stk.stride = P.spill_stride;
+    Stats st = {0, 0, 0, 0, 0};
+    unsigned long long paths = 0;
+    const size_t n_pixels = (size_t)P.width * P.height;
+    const vec3 S = v3(P.eye[0], P.eye[1], P.eye[2]);
+  for (int unit = blockIdx.x; unit < n_units;) {
+    const int tile = unit % n_tiles, group = unit / n_tiles;
     const int ix = (tile % tilesx) * 8 + (lane & 7), iy = (tile / tilesx) * 8 + (lane >> 3);
     const bool inside = ix < P.width && iy < P.height;
     const int f0 = group * P.unit_frames;
     const int nf = P.frame_count - f0 < P.unit_frames ? P.frame_count - f0 : P.unit_frames;
-    LaneStack stk;
-    stk.lds = &s_stack[lane], stk.lstride = kWave, stk.spill = nullptr, stk.stride = 0;
-    Stats st = {0, 0, 0, 0, 0};
-    unsigned long long paths = 0;
-    const size_t n_pixels = (size_t)P.width * P.height;
-    float4* const region = P.states + (size_t)blockIdx.x * (size_t)(P.unit_frames * kWave) * 4;
+    float4* const region = P.states + (size_t)unit * (size_t)(P.unit_frames * kWave) * 4;
     const float pixx = -1.0f + 2.0f * ((float)ix + 0.5f) / (float)P.width;
     const float pixy = -1.0f + 2.0f * ((float)iy + 0.5f) / (float)P.height;
-    const vec3 S = v3(P.eye[0], P.eye[1], P.eye[2]);
     int count = 0;  // wave-uniform: states written so far
     for (int k = 0; k < nf; ++k) {
         const int fidx = f0 + k;
@@ -1117,7 +1224,8 @@ __global__ void __launch_bounds__(kWave) first_kernel(const RenderParams P) {
             dir.z = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
             const vec3 d = normalize(dir);
             float t;
-            const int tri = hitBVH<false, TIE_SHADER, STATS, false>(sc, stk, S, d, &t, st, P.stats_executed != 0);
+            const int tri = ENTRY ? hitBVH_entry<STATS, SPILL>(sc, stk, S, d, &t, st)
+                                  : hitBVH<false, TIE_SHADER, STATS, SPILL>(sc, stk, S, d, &t, st, P.stats_executed != 0);
             if (tri < 0) {
                 vec3 color = v3(0);  // f5:945 / f4:557: the environment along the camera ray
                 if (sc.hdr) {
@@ -1161,7 +1269,14 @@ __global__ void __launch_bounds__(kWave) first_kernel(const RenderParams P) {
         }
         count += __popcll(m);
     }
-    if (lane == 0) P.unit_count[blockIdx.x] = count;
+    if (lane == 0) P.unit_count[unit] = count;
+    if ((int)gridDim.x >= n_units) break;  // one wave per unit
+    // persistent waves: units 0 .. gridDim.x - 1 went to the waves by number, the rest through a counter (a spare word of
+    // the path loop's queue block, zeroed with it before the launch; the path loop starts after this kernel has ended)
+    unsigned nx = 0;
+    if (lane == 0) nx = __hip_atomic_fetch_add(P.queue + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unit = (int)gridDim.x + __builtin_amdgcn_readfirstlane((int)nx);
+  }
     if (STATS) flush_stats(P, st, paths);
 }
 
@@ -1600,9 +1715,9 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         P.queue = w.queue, P.samples = w.samples, P.sobol = w.sobol, P.spill = w.spill;
         P.states = w.states, P.unit_count = w.unit_count, P.cp = w.cp;
         // two-kernel form: where the workspace has room for the path states, the tree fits the LDS stack and no entry BVH is walked
-        const bool seg = w.states != nullptr && !spill && !entry;
+        const bool seg = w.states != nullptr;
         if (ws.camera_only && !seg)
-            return set_error(RT_ERR_INVALID_ARG, "rt_render_stats_camera: this scene renders with the one-kernel path loop (entry BVH, BVH deeper than %d, or rt_tuning.single_kernel): the camera rays are not a kernel of their own", kLdsDepth);
+            return set_error(RT_ERR_INVALID_ARG, "rt_render_stats_camera: this scene renders with the one-kernel path loop (rt_tuning.single_kernel): the camera rays are not a kernel of their own");
         const bool piped = w.owner && w.own_stream;
         const hipStream_t rstream = piped ? w.owner->stream : stream;
         // the slot's previous user — overlapped or not, on whatever stream — has folded its samples (a wait on an event
@@ -1620,13 +1735,21 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
                 HIPCHK(hipEventCreate(&tl.a0));
                 HIPCHK(hipEventRecord(tl.a0, rstream));
             }
-            // one wave per unit (tile x unit_frames frames); it leaves unit_count[unit] and the unit's states for the path loop
+            // a wave per unit (tile x unit_frames frames): it leaves unit_count[unit] and the unit's states for the path loop.
+            // Deep trees: persistent waves (the global part of the stacks is sized for the path loop's thread count)
+            const unsigned fgrid = (unsigned)(spill ? (n_units < blocks ? n_units : blocks) : n_units);
+#define FIRST3(MODE_, SPILL_, ENTRY_) hipLaunchKernelGGL((first_kernel<MODE_, STATS, SPILL_, ENTRY_>), dim3(fgrid), dim3(kWave), 0, rstream, P, (int)n_units)
+#define FIRST2(MODE_, SPILL_) do { if (entry) FIRST3(MODE_, SPILL_, true); else FIRST3(MODE_, SPILL_, false); } while (0)
+#define FIRST(MODE_) do { if (spill) FIRST2(MODE_, true); else FIRST2(MODE_, false); } while (0)
             if (d->mode == RT_MODE_CHAP5)
-                hipLaunchKernelGGL((first_kernel<RT_MODE_CHAP5, STATS>), dim3((unsigned)n_units), dim3(kWave), 0, rstream, P);
+                FIRST(RT_MODE_CHAP5);
             else if (d->mode == RT_MODE_CHAP4)
-                hipLaunchKernelGGL((first_kernel<RT_MODE_CHAP4, STATS>), dim3((unsigned)n_units), dim3(kWave), 0, rstream, P);
+                FIRST(RT_MODE_CHAP4);
             else
-                hipLaunchKernelGGL((first_kernel<RT_MODE_CHAP3, STATS>), dim3((unsigned)n_units), dim3(kWave), 0, rstream, P);
+                FIRST(RT_MODE_CHAP3);
+#undef FIRST
+#undef FIRST2
+#undef FIRST3
             HIPCHK(hipGetLastError());
         }
         if (ws.camera_only) continue;
@@ -1635,18 +1758,23 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
             HIPCHK(hipEventCreate(&tl.b));
             HIPCHK(hipEventRecord(tl.a, rstream));
         }
-#define LAUNCH2(MODE_, SPILL_)                                                                                  \
+#define LAUNCH3(MODE_, SPILL_, ENTRY_)                                                                          \
     do {                                                                                                        \
-        if (entry)                                                                                              \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, SPILL_, true, false>), dim3(grid), dim3(kWave), 0, rstream, P);  \
+        if (seg)                                                                                                \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, SPILL_, ENTRY_, true>), dim3(grid), dim3(kWave), 0, rstream, P);  \
         else                                                                                                    \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, SPILL_, false, false>), dim3(grid), dim3(kWave), 0, rstream, P); \
+            hipLaunchKernelGGL((render_kernel<MODE_, STATS, SPILL_, ENTRY_, false>), dim3(grid), dim3(kWave), 0, rstream, P); \
+    } while (0)
+#define LAUNCH2(MODE_, SPILL_)                 \
+    do {                                       \
+        if (entry)                             \
+            LAUNCH3(MODE_, SPILL_, true);      \
+        else                                   \
+            LAUNCH3(MODE_, SPILL_, false);     \
     } while (0)
 #define LAUNCH(MODE_)                  \
     do {                               \
-        if (seg)                       \
-            hipLaunchKernelGGL((render_kernel<MODE_, STATS, false, false, true>), dim3(grid), dim3(kWave), 0, rstream, P); \
-        else if (spill)                \
+        if (spill)                     \
             LAUNCH2(MODE_, true);      \
         else                           \
             LAUNCH2(MODE_, false);     \
@@ -1659,6 +1787,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
             LAUNCH(RT_MODE_CHAP3);
 #undef LAUNCH
 #undef LAUNCH2
+#undef LAUNCH3
         HIPCHK(hipGetLastError());
         if (timed) {
             HIPCHK(hipEventRecord(tl.b, rstream));
@@ -1696,7 +1825,7 @@ static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count
     const size_t threads = (size_t)render_blocks(s) * kWave;
     const size_t spill = spill_bytes_needed(s, threads);
     // two-kernel form (first_kernel -> render_kernel<..., SEG>): every sample slot of a unit may leave a 64-byte path state
-    const bool seg = !s->tuning.single_kernel && !spill && !s->dev.has_entry;
+    const bool seg = !s->tuning.single_kernel;
     const size_t n_tiles = (size_t)((d->width + 7) / 8) * (size_t)((d->height + 7) / 8);
     const size_t state_per_frame = seg ? n_tiles * kWave * 4 * sizeof(float4) : 0;
     while (launch_frames > 1 && (per_frame + state_per_frame) * launch_frames > kMaxSampleBytes) launch_frames >>= 1;

@@ -31,10 +31,18 @@ pmc pmc_write WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -- $C5
 pmc pmc_ta TA_TA_BUSY_sum TA_BUSY_avr TD_TD_BUSY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE -- $C5
 cd "$root"
 if [ -z "$quick" ]; then
+# the other configurations (config 2 at r = 4 / 1.7, config 4 at its start-up camera and with the sphere filling the frame, the
+# config-5 scene in chapter-3 mode, one frame per call): rates + the kernel trace of the same command
+timeout -k 10 300 python3 -u tools/perf_matrix.py --cases c5,c3,c4,c4fill,one,prim --spp 64 --stats > "$out/matrix.log" 2>&1 || { tail "$out/matrix.log"; exit 1; }
+cd /tmp
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$out/matrix_stats" -o r -- python3 "$root/tools/perf_matrix.py" --cases c5,c3,c4,c4fill,prim --spp 64 > "$out/matrix_under_rocprof.log" 2>&1 || exit 1
+cd "$root"
+# a sustained run: 512 launches of 64 frames (>= 10 s), kernel time and measured shader clock over the whole run
+timeout -k 10 300 python3 "$B" --steps 512 --warmup 2 --no-cpu-baseline > "$out/sustained.json.log" 2> "$out/sustained.err" || { tail "$out/sustained.err"; exit 1; }
 timeout -k 10 600 python3 -u tools/baselines.py > "$out/baselines.log" 2>&1 || { tail "$out/baselines.log"; exit 1; }
 # the synthetic ~10 M-triangle workload at 4K (BASELINE configs[4]); the scene build is cached under /tmp for the passes
 SYN="--scene synthetic --width 3840 --height 2160 --spp 8 --no-cpu-baseline"
-timeout -k 10 600 python3 "$B" $SYN --steps 4 --warmup 1 > "$out/syn_bench.json.log" 2> "$out/syn_bench.err" || { tail "$out/syn_bench.err"; exit 1; }
+timeout -k 10 600 python3 "$B" $SYN --steps 16 --warmup 2 > "$out/syn_bench.json.log" 2> "$out/syn_bench.err" || { tail "$out/syn_bench.err"; exit 1; }
 cd /tmp
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d "$out/syn_stats" -o r -- python3 "$B" $SYN --steps 4 --warmup 1 > "$out/syn_bench_under_rocprof.log" 2>&1 || exit 1
 pmc syn_pmc_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $SYN --steps 1 --warmup 1 --no-stats

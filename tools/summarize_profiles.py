@@ -102,12 +102,12 @@ def main():
     except OSError:
         pass
     all_stats = {}
-    for sub, suffix in (("stats", ""), ("syn_stats", "_synthetic")):
+    for sub, suffix in (("stats", ""), ("syn_stats", "_synthetic"), ("matrix_stats", "_matrix")):
         db = first_db(os.path.join(src, sub))
         if not db:
             continue
         stats = kernel_stats(db)
-        all_stats["syn_" if suffix else ""] = stats
+        all_stats[{"": "", "_synthetic": "syn_", "_matrix": "matrix_"}[suffix]] = stats
         with open(dst + suffix + "_kernel_stats.csv", "w") as f:
             f.write("kernel,calls,total_us,avg_us,percent\n")
             for r in stats:
@@ -124,7 +124,8 @@ def main():
                     pmc[os.path.basename(d) + ":first"] = first
     with open(dst + "_pmc.json", "w") as f:
         json.dump(pmc, f, indent=1)
-    for name in ("bench.json.log", "bench_under_rocprof.log", "pytest_gpu.log", "baselines.log", "syn_bench.json.log", "syn_bench_under_rocprof.log"):
+    for name in ("bench.json.log", "bench_under_rocprof.log", "pytest_gpu.log", "baselines.log", "syn_bench.json.log", "syn_bench_under_rocprof.log",
+                 "matrix.log", "sustained.json.log"):
         p = os.path.join(src, name)
         if os.path.isfile(p):
             shutil.copy(p, dst + "_" + name)

@@ -46,14 +46,16 @@ if SYN:
         runk(leaf_lanes=ll, shade_lanes=sl)
     runk()
     sys.exit(0)
-run(32)
-for sl in (32, 40, 56, 64):
-    run(32, shade_lanes=sl)
-for ll in (2, 4, 16, 32):
-    run(32, leaf_lanes=ll)
+run(64)
+run(64)
+for sl in (24, 32, 40, 56, 64):
+    run(64, shade_lanes=sl)
+for ll in (2, 4, 12, 16, 32):
+    run(64, leaf_lanes=ll)
 for wb in (1000, 2000, 8000, 16000):
-    run(32, wait_budget=wb)
-for uf in (1, 4, 8):
-    run(32, unit_frames=uf)
-run(64, launch_frames=64)
-run(64, launch_frames=64, unit_frames=4)
+    run(64, wait_budget=wb)
+for uf in (1, 3, 4, 8):
+    run(64, unit_frames=uf)
+for lf in (32, 128, 256):
+    run(256, launch_frames=lf)
+run(64)
