@@ -69,10 +69,12 @@ def traffic_entry(pmc, prefix="", stats=None, head=None):
         if q1.get("SQ_WAVE_CYCLES"):
             e["first_kernel_wave_wait_fraction"] = q1.get("SQ_WAIT_ANY", 0.0) / q1["SQ_WAVE_CYCLES"]
     # what the figures belong to: bench.py drops them when the kernel it times is no longer this one (> 3 % off)
-    for r in stats or []:
-        if "render_kernel" in r["kernel"] and "kernel_ms_when_profiled" not in e:
+    for r in stats or []:  # (the product kernels: second template argument STATS = false; the statistics passes run the others)
+        args = r["kernel"].split("<", 1)[1].split(",") if "<" in r["kernel"] else []
+        product = len(args) > 1 and args[1].strip().startswith("false")
+        if "render_kernel" in r["kernel"] and product and "kernel_ms_when_profiled" not in e:
             e["kernel_ms_when_profiled"] = r["avg_us"] / 1e3
-        if "first_kernel" in r["kernel"] and "first_kernel_ms_when_profiled" not in e:
+        if "first_kernel" in r["kernel"] and product and "first_kernel_ms_when_profiled" not in e:
             e["first_kernel_ms_when_profiled"] = r["avg_us"] / 1e3
     e["git_head"] = head
     return e
