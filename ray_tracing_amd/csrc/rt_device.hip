@@ -208,7 +208,8 @@ __device__ __forceinline__ int hitBVH(const DevScene& sc, const LaneStack& stk, 
                 const float4 a = sc.ttri[i * 3 + 0], b = sc.ttri[i * 3 + 1], c = sc.ttri[i * 3 + 2];
                 float t;
                 if (STATS) st.tris++;
-                if (hitTriangleT(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), S, d, &t)) {
+                // (statistics builds count every improvement inside a leaf, f5:250-253: no cut-off there)
+                if (hitTriangleT(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), S, d, &t, STATS ? __builtin_inff() : best)) {
                     // shader (f5:250, 278): strict < in visit order => the first visited candidate keeps a tie.
                     // chap2 (c2:457, 512): minimum over all visited leaves; a tie goes to the right-most leaf
                     // (larger first index) and, inside a leaf, to the lowest index.
@@ -1186,7 +1187,7 @@ __global__ void __launch_bounds__(256) cp_table_kernel(float2* out, int width, i
 // persistent waves with a static stride were measured 25 % slower on config 5); deep trees (SPILL) bound the global spill buffer
 // with persistent waves — as many as the path loop uses — that take their next unit from a counter.  ENTRY: hitBVH_entry.
 template <int MODE, bool STATS, bool SPILL, bool ENTRY>
-__global__ void __launch_bounds__(kWave) first_kernel(const RenderParams P, int n_units) {
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(ENTRY ? 5 : 8))) first_kernel(const RenderParams P, int n_units) {
     __shared__ int s_stack[kLdsDepth * kWave];
     const DevScene& sc = P.sc;
     const int lane = threadIdx.x;

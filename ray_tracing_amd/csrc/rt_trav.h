@@ -74,7 +74,10 @@ RT_HD bool finite3(vec3 v) {
 }
 
 // ---- T1: hitTriangle (distance part), f5:168-209.  N0 = precomputed normalize(cross(p2-p1, p3-p1)). -------------
-RT_HD bool hitTriangleT(vec3 p1, vec3 p2, vec3 p3, vec3 N0, vec3 S, vec3 d, float* t_out) {
+// `t_max` (callers that keep a closest hit): a hit at t > t_max could not be accepted by the caller anyway (acceptance needs
+// t < best, f5:278; chapter 2: t <= best, c2:512), so the inside test is skipped for it — same accept / reject for every t the
+// caller would use; a wave whose lanes all see a triangle beyond their closest hit (coherent camera rays) skips 2/3 of the test.
+RT_HD bool hitTriangleT(vec3 p1, vec3 p2, vec3 p3, vec3 N0, vec3 S, vec3 d, float* t_out, float t_max = __builtin_inff()) {
     // The reference flips N to face the ray first (f5:183-186).  Every later use is odd in N (|dot(N,d)|, the quotient
     // of two dot products with N, the signs of a,b,c tested for "all > 0 or all < 0"), and fp32 negation commutes with
     // round-to-nearest products and sums, so the unflipped normal gives bit-identical t and the same accept/reject.
@@ -82,6 +85,7 @@ RT_HD bool hitTriangleT(vec3 p1, vec3 p2, vec3 p3, vec3 N0, vec3 S, vec3 d, floa
     if (fabs_(dot(N, d)) < 0.00001f) return false;
     const float t = (dot(N, p1) - dot(S, N)) / dot(d, N);
     if (t < 0.0005f) return false;
+    if (t > t_max) return false;
     const vec3 P = S + d * t;
     const vec3 c1 = cross(p2 - p1, P - p1);
     const vec3 c2 = cross(p3 - p2, P - p2);
