@@ -41,7 +41,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(rt.Material) == 72          # texels 6..11 of Triangle_encoded
     assert C.sizeof(rt.RenderDesc) == 5 * 4 + 3 * 4 + 16 * 4
     assert C.sizeof(rt.TraceStats) == 48
-    assert C.sizeof(rt.Tuning) == 8 * 4 and C.sizeof(rt.SceneInfo) == 10 * 4 and C.sizeof(rt.KernelTiming) == 16
+    assert C.sizeof(rt.Tuning) == 9 * 4 and C.sizeof(rt.SceneInfo) == 10 * 4 and C.sizeof(rt.KernelTiming) == 20
 
 
 def test_errors_are_codes_not_aborts(tmp_path):
