@@ -1036,6 +1036,23 @@ def test_hdr_cache_on_the_gpu_equals_the_host_table(hdr_pair):
     assert abs(float(cache.reshape(-1)[23]) - 5.94006e-07) < 1e-12
 
 
+def test_render_from_a_scene_loaded_from_the_on_disk_cache(scene_small, hdr_pair, tmp_path):
+    """SURVEY 8(f)1 end to end on the GPU: Triangle_encoded[] / BVHNode_encoded[] saved to the scene cache, loaded back and
+    rendered — the image equals the oracle's on the original arrays (the cache stores the reference's own layouts, raw fp32)."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    path = str(tmp_path / "small.rtsc")
+    rt.scene_cache_save(path, 0xC0FFEE, tris, nodes)
+    t2, n2 = rt.scene_cache_load(path, 0xC0FFEE)
+    assert np.array_equal(t2.view(np.uint32), np.asarray(tris, np.float32).reshape(-1, 36).view(np.uint32))
+    sc = rt.Scene(t2, n2, hdr, cache)
+    eye, cam = rt.camera(40.0, 22.0, 3.3)
+    d = rt.make_desc(90, 70, mode=5, eye=eye, camera_rotate=cam)
+    ref, ost = O.render(tris, nodes, hdr, cache, 90, 70, 5, eye, cam, 0, 3)
+    _assert_images_equal(sc.render(d, 0, 3), ref, "scene from the cache file")
+    assert sc.render_stats(d, 0, 3) == ost
+
+
 def test_render_multi_replicas_in_one_process(scene_small, hdr_pair):
     """rt_render_multi: three replicas of the scene (here all on the box's one GPU; one per device in production) render disjoint
     frame ranges concurrently and their SUM buffers are added in replica order: two steps of it equal the oracle's sums added in

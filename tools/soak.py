@@ -1,5 +1,6 @@
 """Termination soak: many launches of random sizes / frame ranges / modes / scenes / tuning knobs; prints progress lines.
-No oracle comparison (the parity tests do that): the point is that every launch drains its queue and returns."""
+Every launch must drain its queue and return; the smaller device-buffer launches are also checked bit for bit against the same
+frames rendered with default tuning through the host-buffer entry point (the oracle comparison itself is the parity tests' job)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
@@ -21,7 +22,7 @@ try:
 except Exception:  # noqa: BLE001
     use_torch = False
 keep = []
-t0 = time.time(); k = 0; paths = 0
+t0 = time.time(); k = 0; paths = 0; checked = 0
 while time.time() - t0 < budget:
     sc = objs[rng.randint(len(objs))]
     W, H = int(rng.randint(1, 700)), int(rng.randint(1, 400))
@@ -30,7 +31,7 @@ while time.time() - t0 < budget:
     sc.set_tuning(launch_frames=rng.choice([1, 2, 5, 32, 64]), unit_frames=rng.choice([1, 2, 3, 8]),
                   shade_lanes=rng.choice([1, 16, 48, 64]), leaf_lanes=rng.choice([1, 8, 64]),
                   wait_budget=rng.choice([1, 100, 4000, 10**8]), overlap_frames=rng.choice([1, 8, 1025]),
-                  no_cull=rng.choice([0, 0, 1]), no_entry_bvh=rng.choice([0, 0, 1]))
+                  no_cull=rng.choice([0, 0, 1]), no_entry_bvh=rng.choice([0, 0, 1]), single_kernel=rng.choice([0, 0, 1]))
     cam_args = (float(rng.uniform(0, 360)), float(rng.uniform(-89, 89)), float(rng.uniform(0.05, 8)))
     eye, cam = rt.camera(*cam_args)
     d = rt.make_desc(W, H, mode=mode, eye=eye, camera_rotate=cam, accumulate=int(rng.randint(2)))
@@ -49,10 +50,18 @@ while time.time() - t0 < budget:
         assert img.shape == (H, W, 3)
     else:
         st = streams[int(rng.randint(len(streams)))]
-        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
         with torch.cuda.stream(st):
+            acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")  # (zero fill on the stream that renders)
             if how == 2 or W * H * 12 > (40 << 20):
                 sc.render_device(d, fb, F, acc.data_ptr(), st.cuda_stream)
+                if W * H * F <= 2_000_000:  # image check: the same frames, default tuning, host-buffer entry point
+                    torch.cuda.synchronize()
+                    got = acc.cpu().numpy()
+                    sc.set_tuning()
+                    want = sc.render(d, fb, F)
+                    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+                    assert same.all(), f"launch {k}: {int((~same).sum())} floats differ from the default-tuning render"
+                    checked += 1
             elif how == 3:
                 try:
                     sc.render_device_noalloc(d, fb, min(F, 3), acc.data_ptr(), st.cuda_stream)
@@ -71,4 +80,4 @@ while time.time() - t0 < budget:
         print(f"{k} launches, {paths / 1e6:.0f} Mpaths, {time.time() - t0:.0f} s", flush=True)
 if use_torch:
     torch.cuda.synchronize()
-print(f"soak ok: {k} launches, {paths / 1e6:.0f} Mpaths in {time.time() - t0:.0f} s")
+print(f"soak ok: {k} launches ({checked} image-checked), {paths / 1e6:.0f} Mpaths in {time.time() - t0:.0f} s")
