@@ -1199,8 +1199,13 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(ENTR
     unsigned long long paths = 0;
     const size_t n_pixels = (size_t)P.width * P.height;
     const vec3 S = v3(P.eye[0], P.eye[1], P.eye[2]);
-  for (int unit = blockIdx.x; unit < n_units;) {
-    const int tile = unit % n_tiles, group = unit / n_tiles;
+  const int n_groups = n_units / n_tiles;
+  for (int work = blockIdx.x; work < n_units;) {
+    // consecutive waves take the frame groups of ONE tile: nearly the same rays, so the nodes and leaves they fetch are the ones
+    // their neighbours have just pulled into the caches (the unit's number — its region of `states` — stays group-major, as the
+    // path loop's queues hand units out)
+    const int tile = work / n_groups, group = work % n_groups;
+    const int unit = group * n_tiles + tile;
     const int ix = (tile % tilesx) * 8 + (lane & 7), iy = (tile / tilesx) * 8 + (lane >> 3);
     const bool inside = ix < P.width && iy < P.height;
     const int f0 = group * P.unit_frames;
@@ -1276,7 +1281,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(ENTR
     // the path loop's queue block, zeroed with it before the launch; the path loop starts after this kernel has ended)
     unsigned nx = 0;
     if (lane == 0) nx = __hip_atomic_fetch_add(P.queue + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unit = (int)gridDim.x + __builtin_amdgcn_readfirstlane((int)nx);
+    work = (int)gridDim.x + __builtin_amdgcn_readfirstlane((int)nx);
   }
     if (STATS) flush_stats(P, st, paths);
 }
