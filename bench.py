@@ -184,6 +184,11 @@ def main():
         # own stream) overlaps the path loop of step s + 1 on the other buffer; rank 0 adds each reduced buffer to `total`.
         bufs = [renderer.new_buffer() for _ in range(2 if multi else 1)]
         total = renderer.new_buffer() if multi else bufs[0]
+        if multi:
+            # the first use of an operator loads its kernels (52 ms of host time for `add_`, during which the device sat idle too:
+            # measured with RT_BENCH_TRACE=1): pay that here, not inside the first timed step, where only rank 0 would pay it
+            total.add_(bufs[0])
+            total.zero_()
         main_stream = torch.cuda.current_stream(dev)
         stream = main_stream.cuda_stream
         comm_stream = torch.cuda.Stream(dev) if multi else None
@@ -225,10 +230,18 @@ def main():
     if renderer is not None:
         renderer.scene.kernel_timing(reset=True)
     t0 = time.perf_counter()
+    trace = os.environ.get("RT_BENCH_TRACE") == "1"
     for i in range(args.steps):
         step(args.warmup + i)
+        if trace:
+            print(f"[trace] step {i} issued at {(time.perf_counter() - t0) * 1e3:.2f} ms", file=sys.stderr)
+    if trace:
+        torch.cuda.synchronize(dev)
+        print(f"[trace] device idle at {(time.perf_counter() - t0) * 1e3:.2f} ms", file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
+    if trace:
+        print(f"[trace] fence done at {elapsed * 1e3:.2f} ms", file=sys.stderr)
     timing = renderer.scene.kernel_timing(reset=True) if renderer is not None else None
     if multi or rehearsal:
         t = torch.tensor([elapsed], dtype=torch.float64, device=None if rehearsal else dev)
