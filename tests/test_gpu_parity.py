@@ -1013,6 +1013,27 @@ def test_one_kernel_and_two_kernel_forms_of_the_path_loop_agree(scene_small, hdr
         sc.render_stats_camera(d, 2, F)  # one-kernel form: the camera rays are not a kernel of their own
 
 
+def test_4k_config5_scene_both_forms_agree_where_the_state_buffer_cuts_the_launches(scene_chap5, hdr_pair):
+    """3840x2160 (the synthetic config's image size) on the config-5 scene: the two-kernel form's path states (64 B per sample)
+    make the library halve the frames per launch until samples + states fit its 12 GB workspace bound (16 frames at 4K), so a
+    20-frame call is two launches there and one in the one-kernel form.  Same image to the bit (the oracle anchors both forms at
+    1080p and below; at this size the check is form against form, and against an explicit odd cut of the launches)."""
+    tris, nodes = scene_chap5
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(0.0, 20.0, 4.0)
+    W, H, F = 3840, 2160, 20
+    d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+    two = sc.render(d, 3, F)
+    sc.set_tuning(single_kernel=1)
+    one = sc.render(d, 3, F)
+    _assert_images_equal(two, one, "4K, two-kernel form vs one-kernel form")
+    sc.set_tuning(single_kernel=0, launch_frames=7)  # and an explicit, odd cut
+    cut = sc.render(d, 3, F)
+    _assert_images_equal(cut, one, "4K, launches of 7 frames")
+    assert np.isfinite(one).mean() > 0.999 and 0.05 < float(np.nanmean(one)) < 5.0
+
+
 def test_hdr_cache_on_the_gpu_equals_the_host_table(hdr_pair):
     """calculateHdrCache (c5:595-698) on the GPU — rt_hdr_cache_gpu — against the oracle's table and the host
     entry point, to the bit: the bundled 1024x512 map (cache[23] = 5.94006e-07), a random 64x32 map, a ragged 37x19 map
