@@ -202,7 +202,9 @@ int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_beg
  * select the default; rt_scene_set_tuning(s, NULL) restores all defaults.  No counterpart in the reference. */
 typedef struct rt_tuning {
     int32_t launch_frames;     /* frames per kernel launch (sample buffer = W*H*launch_frames*12 B); default 64, max 1024 */
-    int32_t unit_frames;       /* frames per work unit (one 8x8 tile x unit_frames samples); default 2 */
+    int32_t unit_frames;       /* frames per work unit (one 8x8 tile x unit_frames samples); 0 (default, and what
+                                  rt_scene_get_tuning reports for it) = chosen per view: 2; 4 where the scene's root box
+                                  covers at most 40 % of the image (rt_scene_screen_coverage), 8 at 15 % or less: mostly sky */
     int32_t leaf_lanes;        /* lanes holding a leaf that trigger a cooperative leaf pass; default 8 */
     int32_t shade_lanes;       /* lanes waiting for the shade pass that trigger it; default 48 */
     int32_t wait_budget;       /* lane-passes spent waiting that trigger the shade pass; default 4000 */
@@ -245,6 +247,13 @@ typedef struct rt_scene_info {
     float cost_entry_bvh;      /* ... and the entry BVH (0 when none was built) */
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
+
+/* Share of the image (0..1) that the scene's root box can cover from the descriptor's camera (eye, camera_rotate; the camera
+ * model of fshader.fsh:932-937) — an upper bound on the share of camera rays that hit anything; the others take the
+ * environment colour at once (fshader.fsh:945).  1 when no estimate is possible (eye inside or beside the box, a
+ * camera_rotate that is not a rotation, a BVH whose boxes were not validated).  `unit_frames` (optional) receives the frames
+ * per work unit a render call with this descriptor uses (see rt_tuning.unit_frames).  No counterpart in the reference. */
+int rt_scene_screen_coverage(const rt_scene* s, const rt_render_desc* d, float* coverage, int* unit_frames);
 
 /* Traversal statistics of a render (same rays as rt_render): totals over all hitBVH invocations. */
 typedef struct rt_trace_stats {

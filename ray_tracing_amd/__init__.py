@@ -142,6 +142,7 @@ _lib.rt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c
 _lib.rt_scene_get_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
 _lib.rt_scene_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
 _lib.rt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+_lib.rt_scene_screen_coverage.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.POINTER(C.c_float), C.POINTER(C.c_int)]
 _lib.rt_primary_hits.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p]
 _lib.rt_primary_hits_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
@@ -341,6 +342,12 @@ class Scene:
         i = SceneInfo()
         _check(_lib.rt_scene_get_info(self._h, C.byref(i)))
         return i
+
+    def screen_coverage(self, desc: RenderDesc):
+        """(share of the image the scene's root box can cover from desc's camera, frames per work unit a render uses there)."""
+        c, u = C.c_float(0.0), C.c_int(0)
+        _check(_lib.rt_scene_screen_coverage(self._h, C.byref(desc), C.byref(c), C.byref(u)))
+        return float(c.value), int(u.value)
 
     def tuning(self) -> Tuning:
         t = Tuning()

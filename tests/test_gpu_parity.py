@@ -1034,6 +1034,53 @@ def test_4k_config5_scene_both_forms_agree_where_the_state_buffer_cuts_the_launc
     assert np.isfinite(one).mean() > 0.999 and 0.05 < float(np.nanmean(one)) < 5.0
 
 
+def test_unit_size_follows_the_view_and_never_changes_the_image(scene_chap4, hdr_pair):
+    """rt_tuning.unit_frames left at its default: 2 frames per work unit, 4 where the scene's root box covers at most 40 % of the
+    image, 8 at 15 % or less (config 4's start-up camera: 97 % of the camera rays escape, nearly every unit is empty and their
+    number is what costs).
+    rt_scene_screen_coverage reports the estimate and the choice; the image is the oracle's either way."""
+    tris, nodes = scene_chap4
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    W, H, F = 203, 117, 9
+    eye, cam = rt.camera(0.0, 0.0, 4.0)  # c4:147-149: the sphere is a small disc left of the centre
+    far = rt.make_desc(W, H, mode=4, eye=eye, camera_rotate=cam)
+    cov, uf = sc.screen_coverage(far)
+    hits = (sc.primary_hits(far)[0] >= 0).mean()
+    assert 0.0 < hits <= cov <= 0.15 and uf == 8, (hits, cov, uf)
+    assert sc.tuning().unit_frames == 0  # "chosen per view"
+    ref, _ = O.render(tris, nodes, hdr, cache, W, H, 4, eye, cam, 1, F)
+    _assert_images_equal(sc.render(far, 1, F), ref, "mostly sky, units of 8 frames")
+    sc.set_tuning(unit_frames=2)
+    assert sc.screen_coverage(far)[1] == 2 and sc.tuning().unit_frames == 2
+    _assert_images_equal(sc.render(far, 1, F), ref, "mostly sky, units of 2 frames")
+    sc.set_tuning(leaf_lanes=16)  # another knob: the explicit unit size stays
+    assert sc.screen_coverage(far)[1] == 2
+    sc.set_tuning()  # all defaults: back to the per-view choice
+    assert sc.tuning().unit_frames == 0 and sc.screen_coverage(far)[1] == 8
+    sc.set_tuning(single_kernel=1)  # (a get / modify / set round trip keeps the per-view choice)
+    assert sc.screen_coverage(far)[1] == 8
+    _assert_images_equal(sc.render(far, 1, F), ref, "mostly sky, one-kernel form, units of 8 frames")
+    sc.set_tuning()
+    eye2, cam2 = rt.camera(90.0, 45.0, 1.9)  # the sphere fills the frame
+    near = rt.make_desc(W, H, mode=4, eye=eye2, camera_rotate=cam2)
+    cov2, uf2 = sc.screen_coverage(near)
+    assert cov2 > 0.9 and uf2 == 2
+    eye3, cam3 = rt.camera(0.0, 0.0, 2.5)  # in between
+    mid = rt.make_desc(W, H, mode=4, eye=eye3, camera_rotate=cam3)
+    cov3, uf3 = sc.screen_coverage(mid)
+    assert 0.15 < cov3 <= 0.40 and uf3 == 4 and (sc.primary_hits(mid)[0] >= 0).mean() <= cov3
+    ref3, _ = O.render(tris, nodes, hdr, cache, W, H, 4, eye3, cam3, 0, 5)
+    _assert_images_equal(sc.render(mid, 0, 5), ref3, "units of 4 frames")
+    inside = rt.make_desc(W, H, mode=4, eye=(-0.8, 0.8, 0.0), camera_rotate=cam)  # the eye inside the root box: no estimate
+    assert sc.screen_coverage(inside) == (1.0, 2)
+    skew = np.array(cam, np.float32).copy()
+    skew[0] *= 1.5  # not a rotation: no estimate
+    assert sc.screen_coverage(rt.make_desc(W, H, mode=4, eye=eye, camera_rotate=skew)) == (1.0, 2)
+    empty = rt.Scene(np.zeros((0, 36), np.float32), np.zeros((1, 12), np.float32), hdr, cache)
+    assert empty.screen_coverage(far) == (1.0, 2)
+
+
 def test_hdr_cache_on_the_gpu_equals_the_host_table(hdr_pair):
     """calculateHdrCache (c5:595-698) on the GPU — rt_hdr_cache_gpu — against the oracle's table and the host
     entry point, to the bit: the bundled 1024x512 map (cache[23] = 5.94006e-07), a random 64x32 map, a ragged 37x19 map
