@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
     vec3 Lo = v3(0), history = v3(1);
 
 #ifdef RT_OP_CYCLES
-    unsigned long long oc[4] = {0, 0, 0, 0};
+    unsigned long long oc[4] = {0, 0, 0, 0}, acq[2] = {0, 0};
     const long long oc_begin = clock64();
 #endif
     // The launch's samples (pixel, frame) are independent work items.  They are grouped in units (one 8x8 tile x
@@ -722,6 +722,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                 if (asking == 0ull) break;  // wave-uniform
                 if (next_item >= unit_items) {
                     if (queue_empty) break;
+#ifdef RT_OP_CYCLES
+                    const long long acq_t0 = clock64();
+#endif
                     // take a unit: from this XCD's band of tiles first (neighbouring tiles walk the same nodes, and each
                     // XCD has its own L2), then from the next band that still has work
                     int tile = 0, group = 0;
@@ -754,6 +757,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
                         queue_empty = true;
                         break;
                     }
+#ifdef RT_OP_CYCLES
+                    acq[0] += (unsigned long long)(clock64() - acq_t0) + (unsigned long long)(unsigned)(group & 0), acq[1]++;  // (after the count arrived)
+#endif
                     if (SEG) {
                         unit_f0 = tile * (P.unit_frames * kWave), unit_items = group, next_item = 0;  // (its region of `states`, its count)
                         if (unit_items == 0) continue;
@@ -1130,6 +1136,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(RT_W
         oc[3] = (unsigned long long)(clock64() - oc_begin);
         for (int k = 0; k < 4; ++k) atomicAdd(&g_opcycles[k], oc[k]);
         atomicAdd(&g_opcycles[4], 1ull);
+        atomicAdd(&g_opcycles[5], acq[0]), atomicAdd(&g_opcycles[6], acq[1]);
     }
 #endif
 #ifdef RT_SHADE_CYCLES
@@ -2395,6 +2402,8 @@ int rt_kernel_time_ms(float* avg_ms, int* launches, int reset) {
             fprintf(stderr, "[rt cycles] waves %llu, ticks/wave %.0f: INT %.1f%%  LEAF %.1f%%  shade %.1f%%  scheduler+prologue %.1f%%\n", h[4],
                     tot / (double)h[4], 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot,
                     100.0 * (tot - h[0] - h[1] - h[2]) / tot);
+            fprintf(stderr, "[rt cycles] unit acquisitions per wave %.1f, ticks each %.0f = %.2f%% of the wave's ticks\n", (double)h[6] / (double)h[4],
+                    h[6] ? (double)h[5] / (double)h[6] : 0.0, 100.0 * h[5] / tot);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_opcycles), z, sizeof(z));
         }
     }
