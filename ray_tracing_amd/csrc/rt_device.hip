@@ -461,7 +461,9 @@ constexpr int kUnitFrames = 2;     // frames per work unit (one 8x8 tile x this 
 constexpr size_t kMaxSampleBytes = (size_t)12 << 30;  // per-launch workspace: samples (W x H x frames x 12 B) + in the two-kernel form the
                                                       // path states (64 B per sample slot): 1080p x 64 frames = 1.6 + 8.5 GB (288 GB of HBM)
 constexpr int kMaxWidth = 65535, kMaxHeight = 32767;  // a pixel travels as (x | y << 16) in one int
-constexpr int kOverlapFrames = 8;  // launches of fewer frames overlap their neighbours (two workspace slots, internal streams)
+constexpr int kOverlapFrames = 33;  // launches of fewer frames overlap their neighbours (two workspace slots, internal streams); config 5,
+                                    // 1080p, ms per frame without / with overlap: 8 frames per call 0.428 / 0.365, 16: 0.377 / 0.357, 32: 0.355 / 0.344,
+                                    // 64: 0.344 / 0.350 (tools/fpc_probe.py)
 constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
 
 template <bool SPILL>
@@ -1886,7 +1888,7 @@ static void quiesce_slot(rt_scene::Slot& sl) {
 
 // Workspace of the allocating entry points: buffers kept with the scene, grown when a call needs more.  `pipelined`:
 // both slots, path-loop kernels on the slots' streams; otherwise slot 0 alone on the caller's stream (statistics passes).
-static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count, Workspace* ws, bool pipelined) {
+static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count, Workspace* ws, bool pipelined, bool camera_only = false) {
     // frames per kernel launch: bounded by the sample buffer (W x H x frames x RGB fp32)
     int launch_frames = s->tuning.launch_frames;
     if (launch_frames > frame_count) launch_frames = frame_count;
@@ -1894,7 +1896,10 @@ static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count
     const size_t threads = (size_t)render_blocks(s) * kWave;
     const size_t spill = spill_bytes_needed(s, threads);
     // two-kernel form (first_kernel -> render_kernel<..., SEG>): every sample slot of a unit may leave a 64-byte path state
-    const bool seg = !s->tuning.single_kernel;
+    // — except for one-frame launches, the reference's own calling pattern (one frame per display(), c5:706-760): a launch that
+    // short is all ramp-up and drain, and a second kernel in front of it only adds to both (config 5, 1080p, one frame per call:
+    // 0.659 ms in two kernels, 0.605 ms in one; from four frames per call on the two-kernel form wins: tools/fpc_probe.py)
+    const bool seg = !s->tuning.single_kernel && (launch_frames > 1 || camera_only);
     const size_t n_tiles = (size_t)((d->width + 7) / 8) * (size_t)((d->height + 7) / 8);
     const size_t state_per_frame = seg ? n_tiles * kWave * 4 * sizeof(float4) : 0;
     while (launch_frames > 1 && (per_frame + state_per_frame) * launch_frames > kMaxSampleBytes) launch_frames >>= 1;
@@ -2206,7 +2211,7 @@ static int render_stats_impl(rt_scene* s, const rt_render_desc* d, int frame_beg
     unsigned long long h[26] = {0};
     if (e == hipSuccess && frame_count > 0) {
         Workspace ws;
-        rc = scene_workspace(s, d, frame_count, &ws, false);
+        rc = scene_workspace(s, d, frame_count, &ws, false, camera_only);
         ws.camera_only = camera_only;
         if (rc == RT_OK) rc = launch_render<true>(s, d, frame_begin, frame_count, dev, st, nullptr, ws, executed);
         if (rc == RT_OK) {
