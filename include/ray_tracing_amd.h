@@ -276,7 +276,9 @@ int rt_render_stats_executed(rt_scene* s, const rt_render_desc* d, int frame_beg
 int rt_render_stats_camera(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, int executed, rt_trace_stats* out);
 
 /* Average duration (ms) of the path-loop kernel launches made by the calling thread since the last call with
- * reset != 0, measured with HIP events on the launch stream; *launches receives the count. */
+ * reset != 0, measured with HIP events on the launch stream; *launches receives the count.  Launches of fewer than
+ * rt_tuning.overlap_frames frames overlap their neighbours: such a kernel's duration covers a window it shares with the next
+ * launch (set overlap_frames = 1 to time a kernel on its own, as bench.py does for its roofline). */
 int rt_kernel_time_ms(float* avg_ms, int* launches, int reset);
 
 /* The same with the longest launch and the shader clock the path loop ran at: every wave of the path-loop kernel
