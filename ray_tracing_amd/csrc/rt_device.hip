@@ -465,6 +465,7 @@ constexpr int kOverlapFrames = 33;  // launches of fewer frames overlap their ne
                                     // 1080p, ms per frame without / with overlap: 8 frames per call 0.428 / 0.365, 16: 0.377 / 0.357, 32: 0.355 / 0.344,
                                     // 64: 0.344 / 0.350 (tools/fpc_probe.py)
 constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
+constexpr int kLeafLanesBig = 16, kHandlerLanesBig = 24;  // the same two thresholds for scenes with an entry BVH (rt_scene_set_tuning)
 
 template <bool SPILL>
 __device__ __forceinline__ void wstack_push(int* lds, int* spill, long long stride, int sp, int v) {
@@ -1611,6 +1612,7 @@ int rt_scene_create_ex(const float* tris, int nT, const float* nodes, int nN, co
     s->dev.climb_eps = climb_eps;
     s->dev.root_entry2 = root_entry2;
     s->dev.has_entry = has_entry ? 1 : 0;
+    (void)rt_scene_set_tuning(s, nullptr);  // the defaults for THIS scene (they depend on whether it has an entry BVH)
     *out = s;
     return RT_OK;
 }
@@ -2047,7 +2049,12 @@ int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out) {
 
 int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     if (!s) return set_error(RT_ERR_INVALID_ARG, "rt_scene_set_tuning: NULL scene");
-    const rt_tuning def = {kLaunchFrames, kUnitFrames, kLeafLanes, kHandlerLanes, kWaitBudget, 0, kOverlapFrames, 0, 0};
+    // Scheduler thresholds: 8 / 48 is the optimum where the scene sits in the caches (config 5, re-swept each round).  A scene
+    // that needed an entry BVH is far beyond them: its walks are chains of cache misses, few lanes come back per pass, and
+    // parking them until 48 have gathered idles too much of the wave — 16 / 24 there: the 10 M-triangle scene at 4K, 8 frames
+    // per step, 999 -> 1117 and 1062 -> 1185 Mpaths/s (the two slot parities; plateau over 12..16 / 16..24, tools/sweep_tuning.py --syn)
+    const rt_tuning def = {kLaunchFrames, kUnitFrames, s->has_entry ? kLeafLanesBig : kLeafLanes, s->has_entry ? kHandlerLanesBig : kHandlerLanes,
+                           kWaitBudget, 0, kOverlapFrames, 0, 0};
     rt_tuning n = t ? *t : def;
     if (n.launch_frames <= 0) n.launch_frames = def.launch_frames;
     if (n.unit_frames <= 0) n.unit_frames = def.unit_frames;
@@ -2119,6 +2126,18 @@ int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int 
         int prio = 0;
         if (hipStreamGetPriority((hipStream_t)stream, &prio) != hipSuccess || prio != 0) overlap = false;
         (void)hipGetLastError();
+    }
+    if (overlap) {
+        // A chain of overlapped launches settles into one of two steady patterns, depending on which of the two internal streams
+        // (slot 0: low priority, slot 1: high) takes the first launch after the device was idle — and they differ: the 10 M-triangle
+        // scene at 4K, 8 frames per call, 64 calls: 1170 Mpaths/s when the chain starts on slot 0, 1115 on slot 1; config 5, 8 frames
+        // per call: 2.98 / 2.93 ms per call, 32: 11.26 / 11.03 (measured, both directions reproducible; the mechanism is the
+        // dispatcher's, not ours).  So a chain that starts on an idle pipeline starts on the slot that suits the scene.
+        bool idle = true;
+        for (int k = 0; k < 2; ++k)
+            if (s->slot[k].fold_recorded && hipEventQuery(s->slot[k].fold_done) != hipSuccess) idle = false;
+        (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error)
+        if (idle) s->next_slot = s->has_entry ? 0u : 1u;
     }
     Workspace ws;
     rc = scene_workspace(s, d, frame_count, &ws, overlap);

@@ -24,27 +24,30 @@ def run(spp, **kw):
     dt = (time.perf_counter() - t0) / 3
     print(f"{kw} spp {spp}: {W * H * spp / dt / 1e6:8.1f} Mpaths/s", flush=True)
 if SYN:
-    def runk(**kw):  # kernel time (HIP events inside the library), launches of 8 frames: not overlapped
+    W, H = 3840, 2160  # the bench line's shape: 4K, 8 frames per step, consecutive launches overlapped
+    d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    def runk(**kw):
         sc.set_tuning()
         sc.set_tuning(**kw)
         sc.render_device(d, 0, 8, acc.data_ptr(), st); torch.cuda.synchronize()
-        rt.kernel_time_ms(reset=True)
-        for i in range(3):
+        t0 = time.perf_counter()
+        for i in range(N):
             sc.render_device(d, (i + 1) * 8, 8, acc.data_ptr(), st)
         torch.cuda.synchronize()
-        ms, n = rt.kernel_time_ms(reset=True)
-        print(f"{str(kw):60s} kernel {ms:8.2f} ms  {W * H * 8 / ms / 1e3:8.1f} Mpaths/s", flush=True)
-    runk()
-    runk()
-    for sl in (16, 24, 32, 40, 56):
-        runk(shade_lanes=sl)
-    for ll in (4, 12, 16, 20):
-        runk(leaf_lanes=ll)
-    for wb in (500, 1000, 2000, 16000):
-        runk(wait_budget=wb)
-    for ll, sl in ((12, 24), (12, 32), (16, 24), (16, 32), (12, 40)):
-        runk(leaf_lanes=ll, shade_lanes=sl)
-    runk()
+        ms = (time.perf_counter() - t0) / N * 1e3
+        print(f"{str(kw):60s} {ms:8.2f} ms per 8-frame 4K step  {W * H * 8 / ms / 1e3:8.1f} Mpaths/s", flush=True)
+    N = 15  # odd, plus the warm-up launch: every figure starts on the slot the previous one started on; `flip` changes it
+    for flip in (0, 1):
+        if flip:
+            sc.render_device(d, 0, 8, acc.data_ptr(), st)
+        for kw in ({}, {"leaf_lanes": 16, "shade_lanes": 24}, {"leaf_lanes": 16, "shade_lanes": 20}, {"leaf_lanes": 16, "shade_lanes": 16},
+                   {"leaf_lanes": 12, "shade_lanes": 24}, {"leaf_lanes": 12, "shade_lanes": 20}, {"leaf_lanes": 8, "shade_lanes": 24},
+                   {"leaf_lanes": 16, "shade_lanes": 24, "wait_budget": 2000}, {"leaf_lanes": 16, "shade_lanes": 24, "wait_budget": 8000},
+                   {"leaf_lanes": 16, "shade_lanes": 24, "unit_frames": 4}, {}):
+            runk(**kw)
+    runk(overlap_frames=1)
+    runk(single_kernel=1)
     sys.exit(0)
 run(64)
 run(64)
