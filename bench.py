@@ -61,6 +61,8 @@ def parse_args(argv=None):
     ap.add_argument("--cache-dir", default="/tmp", help="where the synthetic scene's BVH is cached between runs")
     ap.add_argument("--up-angle", type=float, default=20.0)
     ap.add_argument("--single-kernel", action="store_true", help="rt_tuning.single_kernel = 1: the one-kernel form of the path loop")
+    ap.add_argument("--no-overlap", action="store_true", help="rt_tuning.overlap_frames = 1: every launch on its own (profiling passes: a kernel's "
+                                                              "duration in a trace then is its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check the accumulated image against a 1-GPU render of the same frames")
@@ -114,6 +116,8 @@ class GpuRenderer:
         self.scene = rt.Scene(tris, nodes, self.hdr, self.cache, device=local_rank)
         if args.single_kernel:
             self.scene.set_tuning(single_kernel=1)
+        if args.no_overlap:
+            self.scene.set_tuning(overlap_frames=1)
         # orbit camera of c5:716-720 at r = 4 (c5:149), raised 20 degrees: at the start-up upAngle = 0 the eye sits under the
         # floor slab (y = 0.2) and sees only its underside, so the first thing a user does is drag the view up
         self.eye, self.cam = rt.camera(0.0, args.up_angle, 4.0)

@@ -44,7 +44,7 @@ timeout -k 10 600 python3 -u tools/baselines.py > "$out/baselines.log" 2>&1 || {
 SYN="--scene synthetic --width 3840 --height 2160 --spp 8 --no-cpu-baseline"
 timeout -k 10 600 python3 "$B" $SYN --steps 16 --warmup 2 > "$out/syn_bench.json.log" 2> "$out/syn_bench.err" || { tail "$out/syn_bench.err"; exit 1; }
 cd /tmp
-timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d "$out/syn_stats" -o r -- python3 "$B" $SYN --steps 4 --warmup 1 > "$out/syn_bench_under_rocprof.log" 2>&1 || exit 1
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d "$out/syn_stats" -o r -- python3 "$B" $SYN --steps 4 --warmup 1 --no-overlap > "$out/syn_bench_under_rocprof.log" 2>&1 || exit 1
 pmc syn_pmc_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $SYN --steps 1 --warmup 1 --no-stats
 pmc syn_pmc_fetch FETCH_SIZE TCC_HIT_sum -- $SYN --steps 1 --warmup 1 --no-stats
 pmc syn_pmc_write WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -- $SYN --steps 1 --warmup 1 --no-stats
