@@ -1787,7 +1787,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         const WorkSlot& w = ws.slot[ws.next_slot ? ((*ws.next_slot)++ % (unsigned)ws.n_slots) : 0];
         P.queue = w.queue, P.samples = w.samples, P.sobol = w.sobol, P.spill = w.spill;
         P.states = w.states, P.unit_count = w.unit_count, P.cp = w.cp;
-        // two-kernel form: where the workspace has room for the path states, the tree fits the LDS stack and no entry BVH is walked
+        // two-kernel form: where scene_workspace gave the slot a path-state buffer (launches of two or more frames, unless rt_tuning.single_kernel)
         const bool seg = w.states != nullptr;
         if (ws.camera_only && !seg)
             return set_error(RT_ERR_INVALID_ARG, "rt_render_stats_camera: this scene renders with the one-kernel path loop (rt_tuning.single_kernel): the camera rays are not a kernel of their own");
