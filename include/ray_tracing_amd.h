@@ -206,7 +206,8 @@ typedef struct rt_tuning {
                                   rt_scene_get_tuning reports for it) = chosen per view: 2; 4 where the scene's root box
                                   covers at most 40 % of the image (rt_scene_screen_coverage), 8 at 15 % or less: mostly sky */
     int32_t leaf_lanes;        /* lanes holding a leaf that trigger a cooperative leaf pass; default 8 (16 on a scene with an entry BVH) */
-    int32_t shade_lanes;       /* lanes waiting for the shade pass that trigger it; default 48 (24 on a scene with an entry BVH) */
+    int32_t shade_lanes;       /* lanes waiting for the shade pass that trigger it; 0 (default, and what rt_scene_get_tuning
+                                  reports for it) = 48; 24 on a scene with an entry BVH; 36 in chapter-3 mode */
     int32_t wait_budget;       /* lane-passes spent waiting that trigger the shade pass; default 4000 */
     int32_t no_cull;           /* > 0: walk every node whose box the ray hits, as the reference does (f5:295-307), instead
                                   of skipping subtrees that provably cannot hold a closer hit; default 0 (skip them) */

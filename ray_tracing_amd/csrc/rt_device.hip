@@ -465,6 +465,7 @@ constexpr int kOverlapFrames = 33;  // launches of fewer frames overlap their ne
                                     // 1080p, ms per frame without / with overlap: 8 frames per call 0.428 / 0.365, 16: 0.377 / 0.357, 32: 0.355 / 0.344,
                                     // 64: 0.344 / 0.350 (tools/fpc_probe.py)
 constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
+constexpr int kHandlerLanesChap3 = 36;
 constexpr int kLeafLanesBig = 16, kHandlerLanesBig = 24;  // the same two thresholds for scenes with an entry BVH (rt_scene_set_tuning)
 
 template <bool SPILL>
@@ -1452,6 +1453,7 @@ struct rt_scene {
     float root_box[6] = {0, 0, 0, 0, 0, 0};    // AA, BB of the caller's root node (valid only where the BVH's boxes were validated)
     bool root_box_ok = false;
     bool unit_frames_auto = true;              // rt_tuning.unit_frames was left at its default: the unit follows the view
+    bool shade_lanes_auto = true;              // rt_tuning.shade_lanes was left at its default: it follows the scene and the mode
 };
 
 extern "C" {
@@ -1713,7 +1715,9 @@ static void fill_params(const rt_scene* s, const rt_render_desc* d, RenderParams
     memcpy(P->cam, d->camera_rotate, sizeof(P->cam));
     P->leaf_lanes = s->tuning.leaf_lanes;
     P->wait_budget = s->tuning.wait_budget;
-    P->refill = s->tuning.shade_lanes;
+    // (chapter 3's diffuse shade pass is a fraction of chapter 5's: it pays earlier — config-5 scene, 1080p: 7766 -> 8040 Mpaths/s at 36
+    // waiting lanes instead of 48; chapter 4: 48 or 40 within 1.5 % either way, scene-dependent; tools/mode_probe.py)
+    P->refill = (s->shade_lanes_auto && d->mode == RT_MODE_CHAP3 && !s->has_entry) ? kHandlerLanesChap3 : s->tuning.shade_lanes;
     P->unit_frames = effective_unit_frames(s, d);
 }
 
@@ -2044,6 +2048,7 @@ int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out) {
     if (!s || !out) return set_error(RT_ERR_INVALID_ARG, "rt_scene_get_tuning: NULL argument");
     *out = s->tuning;
     if (s->unit_frames_auto) out->unit_frames = 0;  // (0 = chosen per view: a get / modify / set round trip keeps it that way)
+    if (s->shade_lanes_auto) out->shade_lanes = 0;  // (0 = chosen per scene and mode)
     return RT_OK;
 }
 
@@ -2073,6 +2078,7 @@ int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     n.single_kernel = n.single_kernel > 0 ? 1 : 0;
     s->tuning = n;
     s->unit_frames_auto = !(t && t->unit_frames > 0);
+    s->shade_lanes_auto = !(t && t->shade_lanes > 0);
     s->dev.has_entry = (s->has_entry && !n.no_entry_bvh && !n.no_cull) ? 1 : 0;
     return RT_OK;
 }

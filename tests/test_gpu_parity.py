@@ -1049,15 +1049,16 @@ def test_unit_size_follows_the_view_and_never_changes_the_image(scene_chap4, hdr
     hits = (sc.primary_hits(far)[0] >= 0).mean()
     assert 0.0 < hits <= cov <= 0.15 and uf == 8, (hits, cov, uf)
     assert sc.tuning().unit_frames == 0  # "chosen per view"
+    assert sc.tuning().shade_lanes == 0  # "chosen per scene and mode" (48; 24 with an entry BVH; 36 in chapter-3 mode)
     ref, _ = O.render(tris, nodes, hdr, cache, W, H, 4, eye, cam, 1, F)
     _assert_images_equal(sc.render(far, 1, F), ref, "mostly sky, units of 8 frames")
     sc.set_tuning(unit_frames=2)
     assert sc.screen_coverage(far)[1] == 2 and sc.tuning().unit_frames == 2
     _assert_images_equal(sc.render(far, 1, F), ref, "mostly sky, units of 2 frames")
-    sc.set_tuning(leaf_lanes=16)  # another knob: the explicit unit size stays
-    assert sc.screen_coverage(far)[1] == 2
+    sc.set_tuning(leaf_lanes=16, shade_lanes=20)  # other knobs: the explicit unit size stays
+    assert sc.screen_coverage(far)[1] == 2 and sc.tuning().shade_lanes == 20 and sc.tuning().leaf_lanes == 16
     sc.set_tuning()  # all defaults: back to the per-view choice
-    assert sc.tuning().unit_frames == 0 and sc.screen_coverage(far)[1] == 8
+    assert sc.tuning().unit_frames == 0 and sc.tuning().shade_lanes == 0 and sc.screen_coverage(far)[1] == 8
     sc.set_tuning(single_kernel=1)  # (a get / modify / set round trip keeps the per-view choice)
     assert sc.screen_coverage(far)[1] == 8
     _assert_images_equal(sc.render(far, 1, F), ref, "mostly sky, one-kernel form, units of 8 frames")
