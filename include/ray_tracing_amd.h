@@ -223,12 +223,12 @@ typedef struct rt_tuning {
                                   builds a private binned-SAH tree over the same triangles; a ray walks it first, with a
                                   conservative box test, to get a distance bound or to prove it hits nothing, and the caller's
                                   BVH — which alone decides the result — only inside that bound.  Same images, fewer nodes. */
-    int32_t single_kernel;     /* > 0: the whole path loop in one kernel.  Default 0: two kernels per launch of two or more
-                                  frames: the camera rays of all samples — coherent work — are traced first by a plain
-                                  one-lane-per-pixel kernel that also finishes the samples that escape and leaves 64-byte path
-                                  states (8.5 GB per 64-frame 1080p launch) from which the wave-scheduled path loop continues;
-                                  a one-frame launch (the reference's one frame per display()) is all ramp-up and drain and
-                                  runs the one-kernel form.  Same images to the bit. */
+    int32_t single_kernel;     /* 1: the whole path loop in one kernel; 2: two kernels per launch — the camera rays of all samples,
+                                  coherent work, are traced first by a plain one-lane-per-pixel kernel that also finishes the
+                                  samples that escape and leaves 64-byte path states (8.5 GB per 64-frame 1080p launch) from
+                                  which the wave-scheduled path loop continues; 0 (default): two kernels for launches of more
+                                  than 2^22 samples (width x height x frames), one kernel below — a small launch, the reference's
+                                  one frame per display() above all, is all ramp-up and drain.  Same images to the bit. */
 } rt_tuning;
 int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out);
 int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t);

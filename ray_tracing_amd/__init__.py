@@ -314,6 +314,8 @@ class Scene:
         _check(_lib.rt_scene_create_ex(tris.ctypes.data if tris.size else None, tris.shape[0],
                                        nd.ctypes.data if nd.size else None, nd.shape[0], hp, cp, hw, hh,
                                        C.cast(opt, C.c_void_p), C.byref(self._h)))
+        if Scene.default_tuning:
+            self.set_tuning(**Scene.default_tuning)
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:  # (_lib is None while the interpreter shuts down)
@@ -354,10 +356,15 @@ class Scene:
         _check(_lib.rt_scene_get_tuning(self._h, C.byref(t)))
         return t
 
+    default_tuning: dict = {}  # applied to every new Scene and by set_tuning() with no argument (the GPU tests pin the two-kernel
+                               # form of the path loop with it: their images are small, and small launches run the one-kernel form)
+
     def set_tuning(self, **kw):
         """Set some knobs of rt_tuning (others keep their value); set_tuning() with no argument restores the defaults."""
         if not kw:
             _check(_lib.rt_scene_set_tuning(self._h, None))
+            if Scene.default_tuning:
+                self.set_tuning(**Scene.default_tuning)
             return
         t = self.tuning()
         for k, v in kw.items():

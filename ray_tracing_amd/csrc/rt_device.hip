@@ -466,6 +466,7 @@ constexpr int kOverlapFrames = 33;  // launches of fewer frames overlap their ne
                                     // 64: 0.344 / 0.350 (tools/fpc_probe.py)
 constexpr int kLeafLanes = 8;     // run a cooperative leaf pass once this many lanes hold a leaf (or nothing else can run)
 constexpr int kHandlerLanesChap3 = 36;
+constexpr size_t kTwoKernelMinSamples = (size_t)1 << 22;  // launches of fewer samples run the one-kernel form (scene_workspace)
 constexpr int kLeafLanesBig = 16, kHandlerLanesBig = 24;  // the same two thresholds for scenes with an entry BVH (rt_scene_set_tuning)
 
 template <bool SPILL>
@@ -1351,8 +1352,8 @@ __global__ void __launch_bounds__(kBlock) primary_kernel(const RenderParams P) {
 // ---- host side ---------------------------------------------------------------------------------------------------
 
 struct TimedLaunch {
-    hipEvent_t a, b;    // around the path-loop kernel (render_kernel)
-    hipEvent_t a0;      // two-kernel form: before first_kernel (a0 .. a = its duration); else NULL
+    hipEvent_t a = nullptr, b = nullptr;  // around the path-loop kernel (render_kernel) / primary_kernel
+    hipEvent_t a0 = nullptr;              // two-kernel form: before first_kernel (a0 .. a = its duration); else NULL
 };
 static thread_local std::vector<TimedLaunch> g_launches;
 static void destroy_timed(TimedLaunch& tl) {
@@ -1794,7 +1795,7 @@ static int launch_render(rt_scene* s, const rt_render_desc* d, int frame_begin, 
         // two-kernel form: where scene_workspace gave the slot a path-state buffer (launches of two or more frames, unless rt_tuning.single_kernel)
         const bool seg = w.states != nullptr;
         if (ws.camera_only && !seg)
-            return set_error(RT_ERR_INVALID_ARG, "rt_render_stats_camera: this scene renders with the one-kernel path loop (rt_tuning.single_kernel): the camera rays are not a kernel of their own");
+            return set_error(RT_ERR_INVALID_ARG, "rt_render_stats_camera: this scene renders with the one-kernel path loop (rt_tuning.single_kernel = 1): the camera rays are not a kernel of their own");
         const bool piped = w.owner && w.own_stream;
         const hipStream_t rstream = piped ? w.owner->stream : stream;
         // the slot's previous user — overlapped or not, on whatever stream — has folded its samples (a wait on an event
@@ -1902,10 +1903,13 @@ static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count
     const size_t threads = (size_t)render_blocks(s) * kWave;
     const size_t spill = spill_bytes_needed(s, threads);
     // two-kernel form (first_kernel -> render_kernel<..., SEG>): every sample slot of a unit may leave a 64-byte path state
-    // — except for one-frame launches, the reference's own calling pattern (one frame per display(), c5:706-760): a launch that
-    // short is all ramp-up and drain, and a second kernel in front of it only adds to both (config 5, 1080p, one frame per call:
-    // 0.659 ms in two kernels, 0.605 ms in one; from four frames per call on the two-kernel form wins: tools/fpc_probe.py)
-    const bool seg = !s->tuning.single_kernel && (launch_frames > 1 || camera_only);
+    // — except for small launches, the reference's own calling pattern above all (one frame per display(), c5:706-760, in a 512 x 512
+    // window): a launch of a few million samples is all ramp-up and drain, and a second kernel in front of it only adds to both.
+    // Config 5, ms per call in two kernels / in one: 1080p x 1 frame 0.659 / 0.605, x 2 1.02 / 1.02, x 4 1.70 / 1.88; 720p x 4
+    // 0.98 / 0.92, x 8 1.56 / 1.70; 512 x 512 x 8 0.73 / 0.64, x 64 3.47 / 4.18 (tools/fpc_probe.py, tools/small_probe.py): the
+    // crossover sits at about four million samples per launch whatever their shape.
+    const bool seg = s->tuning.single_kernel != 1 &&
+                     (s->tuning.single_kernel == 2 || (size_t)d->width * d->height * (size_t)launch_frames > kTwoKernelMinSamples || camera_only);
     const size_t n_tiles = (size_t)((d->width + 7) / 8) * (size_t)((d->height + 7) / 8);
     const size_t state_per_frame = seg ? n_tiles * kWave * 4 * sizeof(float4) : 0;
     while (launch_frames > 1 && (per_frame + state_per_frame) * launch_frames > kMaxSampleBytes) launch_frames >>= 1;
@@ -2075,7 +2079,7 @@ int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     s->tuning = n;
     s->dev.cull_eps = n.no_cull ? __builtin_inff() : s->cull_eps;
     n.no_entry_bvh = n.no_entry_bvh > 0 ? 1 : 0;
-    n.single_kernel = n.single_kernel > 0 ? 1 : 0;
+    n.single_kernel = n.single_kernel >= 2 ? 2 : (n.single_kernel == 1 ? 1 : 0);  // 0: by launch size, 1: one kernel, 2: two kernels
     s->tuning = n;
     s->unit_frames_auto = !(t && t->unit_frames > 0);
     s->shade_lanes_auto = !(t && t->shade_lanes > 0);

@@ -8,8 +8,28 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+if os.environ.get("RT_ABORT_TRACE"):  # debug aid: C backtrace on SIGABRT (tools/dbg/abort_trace.c, built by hand with gcc)
+    import ctypes
+    _shim = os.path.join(ROOT, "tools", "dbg", "abort_trace.so")
+    if os.path.exists(_shim):
+        ctypes.CDLL(_shim)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "library_default_form: leave the choice between the one- and two-kernel form of the path loop to the library")
+
+
+@pytest.fixture(autouse=True)
+def _pin_two_kernel_form(request):
+    """The parity tests render small images, and launches of fewer than 2^22 samples run the one-kernel form of the path loop by
+    default (rt_tuning.single_kernel = 0).  Pin the two-kernel form — what the full-size configurations run — for every Scene a
+    test creates, unless the test is about the library's own choice; the one-kernel form is covered by the tests that set
+    single_kernel = 1, by every no-allocation test and by tools/soak.py."""
+    import ray_tracing_amd as rt
+    rt.Scene.default_tuning = {} if request.node.get_closest_marker("library_default_form") else {"single_kernel": 2}
+    yield
+    rt.Scene.default_tuning = {}
 
 
 @pytest.fixture(scope="session")

@@ -1082,6 +1082,62 @@ def test_unit_size_follows_the_view_and_never_changes_the_image(scene_chap4, hdr
     assert empty.screen_coverage(far) == (1.0, 2)
 
 
+def test_kernel_timing_after_primary_hits_and_renders(scene_small, hdr_pair):
+    """rt_kernel_timing / rt_kernel_time_ms walk every timed launch of the thread — path-loop launches (with or without a camera-ray
+    kernel in front) and rt_primary_hits launches (never one): regression test for a primary-hits record whose camera-ray event
+    slot was left uninitialised (found when a test first called rt_kernel_timing after rt_primary_hits)."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(10.0, 12.0, 3.2)
+    d = rt.make_desc(96, 64, mode=5, eye=eye, camera_rotate=cam)
+    rt.kernel_time_ms(reset=True)
+    for k in range(40):
+        sc.primary_hits(d)
+        if k % 8 == 0:
+            sc.render(d, k, 2)
+    t = sc.kernel_timing(reset=False)
+    assert t.launches == 45 and t.avg_ms > 0.0 and t.first_avg_ms > 0.0  # (the two-kernel form is pinned for the tests)
+    ms, n = rt.kernel_time_ms(reset=True)
+    assert n == 45 and ms > 0.0
+    assert sc.kernel_timing(reset=True).launches == 0
+
+
+@pytest.mark.library_default_form
+def test_small_launches_run_one_kernel_large_ones_two(scene_small, hdr_pair):
+    """rt_tuning.single_kernel = 0 (default): launches of more than 2^22 samples (width x height x frames) run the two-kernel form,
+    smaller ones — the reference's one frame per display() in a 512 x 512 window — the one-kernel form; 1 / 2 force either.  Which
+    form ran shows in rt_kernel_timing (the camera-ray kernel's duration, 0 when there was none); the image is the oracle's always."""
+    tris, nodes = scene_small
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    assert sc.tuning().single_kernel == 0
+    eye, cam = rt.camera(-25.0, 18.0, 3.1)
+    small = rt.make_desc(320, 200, mode=5, eye=eye, camera_rotate=cam)
+    large = rt.make_desc(1920, 1080, mode=5, eye=eye, camera_rotate=cam)
+    ref, _ = O.render(tris, nodes, hdr, cache, 320, 200, 5, eye, cam, 3, 4)
+
+    def first_kernel_ran(desc, frames):
+        sc.kernel_timing(reset=True)
+        img = sc.render(desc, 3, frames)
+        return sc.kernel_timing(reset=True).first_avg_ms > 0.0, img
+
+    ran, img = first_kernel_ran(small, 4)          # 256 000 samples
+    assert not ran
+    _assert_images_equal(img, ref, "small launch, library's choice (one kernel)")
+    assert first_kernel_ran(large, 4)[0]           # 8.3 M samples
+    assert not first_kernel_ran(large, 2)[0]       # 4.1 M: just below 2^22
+    assert first_kernel_ran(large, 3)[0]
+    sc.set_tuning(single_kernel=2)
+    ran, img = first_kernel_ran(small, 4)
+    assert ran and sc.tuning().single_kernel == 2
+    _assert_images_equal(img, ref, "small launch, two kernels forced")
+    sc.set_tuning(single_kernel=1)
+    assert not first_kernel_ran(large, 4)[0]
+    sc.set_tuning(single_kernel=0, launch_frames=1)  # a long call cut into one-frame launches: each of them is small
+    assert not first_kernel_ran(large, 4)[0]
+
+
 def test_hdr_cache_on_the_gpu_equals_the_host_table(hdr_pair):
     """calculateHdrCache (c5:595-698) on the GPU — rt_hdr_cache_gpu — against the oracle's table and the host
     entry point, to the bit: the bundled 1024x512 map (cache[23] = 5.94006e-07), a random 64x32 map, a ragged 37x19 map
