@@ -1,3 +1,5 @@
+"""Small images (the reference's 512 x 512 window, 1280 x 720), 1 ... 64 frames per call: ms per call with the library's choice of form,
+with one kernel forced and with overlap off.  The numbers behind kTwoKernelMinSamples (rt_device.hip)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
