@@ -328,7 +328,8 @@ def main():
         # above measures that pipeline, but a kernel's event-bracketed duration then covers a window it shares with the next
         # launch.  The roofline needs the kernel's own duration: a few extra steps with overlap off, outside the timed region.
         tun = renderer.scene.tuning()
-        overlapped = min(spp, int(tun.launch_frames)) < int(tun.overlap_frames)
+        shape = renderer.scene.launch_shape(renderer.desc_mean, spp)  # what rt_tuning leaves to the library for this image and call
+        overlapped = bool(shape.overlapped)
         overlapped_ms = None
         if overlapped and not args.no_stats:
             overlapped_ms = {"path_loop": kern_ms, "first_kernel": first_ms}
@@ -359,7 +360,7 @@ def main():
             rays_per_path = ex["rays"] / max(ex["paths"], 1)
             I, Lf, T, Hh = (ex[k] / max(ex["rays"], 1) for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"))
             rI, rLf, rT, rH = (rf[k] / max(rf["rays"], 1) for k in ("internal_nodes", "leaf_nodes", "triangles_tested", "hit_updates"))
-            lf = max(1, int(renderer.scene.tuning().launch_frames))  # frames per kernel launch
+            lf = max(1, int(shape.launch_frames))  # frames per kernel launch
             paths_per_launch = float(W) * H * min(spp, lf)
             launches_per_step = max(1, (spp + lf - 1) // lf)
             scale = paths_per_launch / max(ex["paths"], 1)  # statistics frames -> one launch

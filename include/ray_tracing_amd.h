@@ -201,7 +201,9 @@ int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_beg
 /* Scheduling knobs of the path loop, per scene (they change how the work is cut, never the image: tested).  Fields <= 0
  * select the default; rt_scene_set_tuning(s, NULL) restores all defaults.  No counterpart in the reference. */
 typedef struct rt_tuning {
-    int32_t launch_frames;     /* frames per kernel launch (sample buffer = W*H*launch_frames*12 B); default 64, max 1024 */
+    int32_t launch_frames;     /* frames per kernel launch (sample buffer = W*H*launch_frames*12 B), max 1024; 0 (default, and what
+                                  rt_scene_get_tuning reports for it) = chosen per image size: 2^27 samples per launch, at least 64
+                                  frames (1080p: 64, 1280 x 720: 145, 512 x 512: 512) */
     int32_t unit_frames;       /* frames per work unit (one 8x8 tile x unit_frames samples); 0 (default, and what
                                   rt_scene_get_tuning reports for it) = chosen per view: 2; 4 where the scene's root box
                                   covers at most 40 % of the image (rt_scene_screen_coverage), 8 at 15 % or less: mostly sky */
@@ -256,6 +258,19 @@ int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
  * camera_rotate that is not a rotation, a BVH whose boxes were not validated).  `unit_frames` (optional) receives the frames
  * per work unit a render call with this descriptor uses (see rt_tuning.unit_frames).  No counterpart in the reference. */
 int rt_scene_screen_coverage(const rt_scene* s, const rt_render_desc* d, float* coverage, int* unit_frames);
+
+/* What a render call of `frame_count` frames with this descriptor does on this scene — everything rt_tuning leaves to the
+ * library at 0: frames per launch (image size, workspace bound), frames per work unit (view), whether the camera rays get a
+ * kernel of their own (launch size), whether consecutive launches overlap (when the caller's stream allows it, see
+ * INTEGRATION.md "Streams").  Images never depend on any of it.  No counterpart in the reference. */
+typedef struct rt_launch_shape {
+    int32_t launch_frames;
+    int32_t unit_frames;
+    int32_t two_kernels;
+    int32_t overlapped;
+    float screen_coverage;
+} rt_launch_shape;
+int rt_scene_launch_shape(const rt_scene* s, const rt_render_desc* d, int frame_count, rt_launch_shape* out);
 
 /* Traversal statistics of a render (same rays as rt_render): totals over all hitBVH invocations. */
 typedef struct rt_trace_stats {

@@ -143,6 +143,15 @@ _lib.rt_scene_get_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
 _lib.rt_scene_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
 _lib.rt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
 _lib.rt_scene_screen_coverage.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+
+
+class LaunchShape(C.Structure):
+    """rt_launch_shape"""
+    _fields_ = [("launch_frames", C.c_int32), ("unit_frames", C.c_int32), ("two_kernels", C.c_int32), ("overlapped", C.c_int32),
+                ("screen_coverage", C.c_float)]
+
+
+_lib.rt_scene_launch_shape.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.POINTER(LaunchShape)]
 _lib.rt_primary_hits.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p]
 _lib.rt_primary_hits_device.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.POINTER(TraceStats)]
@@ -350,6 +359,12 @@ class Scene:
         c, u = C.c_float(0.0), C.c_int(0)
         _check(_lib.rt_scene_screen_coverage(self._h, C.byref(desc), C.byref(c), C.byref(u)))
         return float(c.value), int(u.value)
+
+    def launch_shape(self, desc: RenderDesc, frame_count: int) -> LaunchShape:
+        """What a render call of frame_count frames with desc does: frames per launch / per unit, two kernels?, overlapped?"""
+        ls = LaunchShape()
+        _check(_lib.rt_scene_launch_shape(self._h, C.byref(desc), frame_count, C.byref(ls)))
+        return ls
 
     def tuning(self) -> Tuning:
         t = Tuning()

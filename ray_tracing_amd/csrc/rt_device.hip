@@ -1455,6 +1455,7 @@ struct rt_scene {
     bool root_box_ok = false;
     bool unit_frames_auto = true;              // rt_tuning.unit_frames was left at its default: the unit follows the view
     bool shade_lanes_auto = true;              // rt_tuning.shade_lanes was left at its default: it follows the scene and the mode
+    bool launch_frames_auto = true;            // rt_tuning.launch_frames was left at its default: it follows the image size
 };
 
 extern "C" {
@@ -1707,6 +1708,20 @@ static int effective_unit_frames(const rt_scene* s, const rt_render_desc* d) {
     return c <= kSkyCoverage8 ? 8 : (c <= kSkyCoverage4 ? 4 : s->tuning.unit_frames);
 }
 
+// Frames per launch.  rt_tuning.launch_frames when the caller set it; otherwise 64 at 1080p and more on smaller images: a launch
+// ramps up and drains for ~0.5 ms whatever its size, so what matters is its samples — 2^27 of them (1080p x 64) amortise it.
+// 512-frame calls on config 5 (tools/lf_probe.py): 512 x 512 in launches of 64 frames 4842 Mpaths/s, of 512 frames 5838; 1280 x 720 in
+// launches of 64 frames 5770, of 128 or more 5960; 1920 x 1080: 6030 from 32 to 512 frames per launch.  (The workspace bound of
+// scene_workspace — samples + path states <= 12 GB — is the same 2^27 samples x 76 B; larger images get fewer frames there.)
+static int effective_launch_frames(const rt_scene* s, const rt_render_desc* d) {
+    if (!s->launch_frames_auto) return s->tuning.launch_frames;
+    const long long px = (long long)d->width * d->height;
+    long long lf = px > 0 ? ((long long)1 << 27) / px : kLaunchFrames;
+    if (lf < kLaunchFrames) lf = kLaunchFrames;
+    if (lf > kMaxLaunchFrames) lf = kMaxLaunchFrames;
+    return (int)lf;
+}
+
 static void fill_params(const rt_scene* s, const rt_render_desc* d, RenderParams* P) {
     memset(P, 0, sizeof(*P));
     P->sc = s->dev;
@@ -1897,7 +1912,7 @@ static void quiesce_slot(rt_scene::Slot& sl) {
 // both slots, path-loop kernels on the slots' streams; otherwise slot 0 alone on the caller's stream (statistics passes).
 static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count, Workspace* ws, bool pipelined, bool camera_only = false) {
     // frames per kernel launch: bounded by the sample buffer (W x H x frames x RGB fp32)
-    int launch_frames = s->tuning.launch_frames;
+    int launch_frames = effective_launch_frames(s, d);
     if (launch_frames > frame_count) launch_frames = frame_count;
     const size_t per_frame = (size_t)d->width * d->height * 3 * sizeof(float);
     const size_t threads = (size_t)render_blocks(s) * kWave;
@@ -2053,6 +2068,7 @@ int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out) {
     *out = s->tuning;
     if (s->unit_frames_auto) out->unit_frames = 0;  // (0 = chosen per view: a get / modify / set round trip keeps it that way)
     if (s->shade_lanes_auto) out->shade_lanes = 0;  // (0 = chosen per scene and mode)
+    if (s->launch_frames_auto) out->launch_frames = 0;  // (0 = chosen per image size)
     return RT_OK;
 }
 
@@ -2083,6 +2099,7 @@ int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     s->tuning = n;
     s->unit_frames_auto = !(t && t->unit_frames > 0);
     s->shade_lanes_auto = !(t && t->shade_lanes > 0);
+    s->launch_frames_auto = !(t && t->launch_frames > 0);
     s->dev.has_entry = (s->has_entry && !n.no_entry_bvh && !n.no_cull) ? 1 : 0;
     return RT_OK;
 }
@@ -2108,6 +2125,24 @@ int rt_scene_screen_coverage(const rt_scene* s, const rt_render_desc* d, float* 
     return RT_OK;
 }
 
+int rt_scene_launch_shape(const rt_scene* s, const rt_render_desc* d, int frame_count, rt_launch_shape* out) {
+    if (!s || !d || !out) return set_error(RT_ERR_INVALID_ARG, "rt_scene_launch_shape: NULL argument");
+    if (d->width <= 0 || d->height <= 0 || frame_count <= 0) return set_error(RT_ERR_INVALID_ARG, "rt_scene_launch_shape: bad image size %dx%d or frame count %d", d->width, d->height, frame_count);
+    int lf = effective_launch_frames(s, d);
+    if (lf > frame_count) lf = frame_count;
+    const size_t per_frame = (size_t)d->width * d->height * 3 * sizeof(float);
+    const bool want_seg = s->tuning.single_kernel != 1 && (s->tuning.single_kernel == 2 || (size_t)d->width * d->height * (size_t)lf > kTwoKernelMinSamples);
+    const size_t n_tiles = (size_t)((d->width + 7) / 8) * (size_t)((d->height + 7) / 8);
+    const size_t state_per_frame = want_seg ? n_tiles * kWave * 4 * sizeof(float4) : 0;
+    while (lf > 1 && (per_frame + state_per_frame) * lf > kMaxSampleBytes) lf >>= 1;  // (as scene_workspace does)
+    out->launch_frames = lf;
+    out->unit_frames = effective_unit_frames(s, d);
+    out->two_kernels = want_seg ? 1 : 0;
+    out->overlapped = lf < s->tuning.overlap_frames ? 1 : 0;
+    out->screen_coverage = screen_coverage(s, d);
+    return RT_OK;
+}
+
 int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int frame_count, float* accum_dev, void* stream) {
     int rc = check_render_args(s, d, frame_begin, frame_count, accum_dev);
     if (rc != RT_OK) return rc;
@@ -2123,7 +2158,7 @@ int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int 
     //     streams stalls too, and so does handing the internal streams to a second caller stream even on an idle device);
     //   * a priority stream gets its short launches on that stream itself, one after the other.
     // Without overlap (the behaviour of overlap_frames = 1) the library adds no queue of its own to the caller's.
-    const int lf = s->tuning.launch_frames < frame_count ? s->tuning.launch_frames : frame_count;
+    const int lf = effective_launch_frames(s, d) < frame_count ? effective_launch_frames(s, d) : frame_count;
     bool overlap = false;
     if (s->device >= 0 && s->device < kMaxDevices) {
         std::lock_guard<std::mutex> lock(g_overlap_mutex);
@@ -2183,7 +2218,7 @@ int rt_render_device_noalloc(rt_scene* s, const rt_render_desc* d, int frame_beg
         return set_error(RT_ERR_INVALID_ARG, "rt_render_device_noalloc: one %dx%d frame of samples is %zu bytes; the static scratch has room for %zu (limit: width*height <= %zu pixels on this scene)",
                          d->width, d->height, per_frame, room, room / (3 * sizeof(float)));
     size_t lf = room / per_frame;
-    if (lf > (size_t)s->tuning.launch_frames) lf = (size_t)s->tuning.launch_frames;
+    if (lf > (size_t)effective_launch_frames(s, d)) lf = (size_t)effective_launch_frames(s, d);
     if (lf > (size_t)frame_count) lf = (size_t)frame_count;
     ws.slot[0].samples = (float*)(base + off);
     ws.launch_frames = (int)lf;

@@ -1082,6 +1082,39 @@ def test_unit_size_follows_the_view_and_never_changes_the_image(scene_chap4, hdr
     assert empty.screen_coverage(far) == (1.0, 2)
 
 
+@pytest.mark.library_default_form
+def test_launch_shape_follows_image_size_view_and_call(scene_chap5, hdr_pair):
+    """rt_scene_launch_shape reports what rt_tuning leaves to the library: 2^27 samples per launch but at least 64 frames (the
+    workspace bound cuts 4K to 16), two kernels above 2^22 samples per launch, overlap below 33 frames per launch; explicit tuning
+    wins; and a 300-frame call on a small image — one launch now, five before — is still the oracle's image."""
+    tris, nodes = scene_chap5
+    hdr, cache = hdr_pair
+    sc = rt.Scene(tris, nodes, hdr, cache)
+    eye, cam = rt.camera(0.0, 20.0, 4.0)
+    assert sc.tuning().launch_frames == 0
+
+    def shape(w, h, frames):
+        ls = sc.launch_shape(rt.make_desc(w, h, mode=5, eye=eye, camera_rotate=cam), frames)
+        return ls.launch_frames, ls.unit_frames, ls.two_kernels, ls.overlapped
+
+    assert shape(1920, 1080, 1024) == (64, 2, 1, 0)
+    assert shape(1920, 1080, 1) == (1, 2, 0, 1)
+    assert shape(1920, 1080, 2) == (2, 2, 0, 1) and shape(1920, 1080, 3) == (3, 2, 1, 1)
+    assert shape(1280, 720, 1024) == (145, 2, 1, 0)
+    assert shape(512, 512, 1024) == (512, 2, 1, 0) and shape(512, 512, 8) == (8, 2, 0, 1) and shape(512, 512, 40) == (40, 2, 1, 0)
+    assert shape(64, 64, 5000) == (1024, 2, 0, 0)  # (4.2 M samples: exactly 2^22, not above it)
+    assert shape(3840, 2160, 1024) == (16, 2, 1, 1)  # 64 by the rule, 16 by the 12 GB workspace bound
+    sc.set_tuning(launch_frames=7, single_kernel=2, overlap_frames=1)
+    assert shape(1920, 1080, 1024) == (7, 2, 1, 0) and sc.tuning().launch_frames == 7
+    sc.set_tuning()
+    assert sc.tuning().launch_frames == 0 and shape(1920, 1080, 1024) == (64, 2, 1, 0)
+    W, H, F = 96, 60, 300
+    d = rt.make_desc(W, H, mode=5, eye=eye, camera_rotate=cam)
+    assert sc.launch_shape(d, F).launch_frames == F
+    ref, _ = O.render(tris, nodes, hdr, cache, W, H, 5, eye, cam, 0, F)
+    _assert_images_equal(sc.render(d, 0, F), ref, "300 frames in one launch")
+
+
 def test_kernel_timing_after_primary_hits_and_renders(scene_small, hdr_pair):
     """rt_kernel_timing / rt_kernel_time_ms walk every timed launch of the thread — path-loop launches (with or without a camera-ray
     kernel in front) and rt_primary_hits launches (never one): regression test for a primary-hits record whose camera-ray event
