@@ -28,8 +28,8 @@ while time.time() - t0 < budget:
     W, H = int(rng.randint(1, 700)), int(rng.randint(1, 400))
     F = int(rng.choice([1, 1, 2, 3, 7, 33, 70]))
     mode = int(rng.choice([3, 4, 5]))
-    sc.set_tuning(launch_frames=rng.choice([1, 2, 5, 32, 64]), unit_frames=rng.choice([1, 2, 3, 8]),
-                  shade_lanes=rng.choice([1, 16, 48, 64]), leaf_lanes=rng.choice([1, 8, 64]),
+    sc.set_tuning(launch_frames=rng.choice([0, 1, 2, 5, 32, 64]), unit_frames=rng.choice([0, 1, 2, 3, 8]),  # (0: the library's choice)
+                  shade_lanes=rng.choice([0, 1, 16, 48, 64]), leaf_lanes=rng.choice([1, 8, 64]),
                   wait_budget=rng.choice([1, 100, 4000, 10**8]), overlap_frames=rng.choice([1, 8, 1025]),
                   no_cull=rng.choice([0, 0, 1]), no_entry_bvh=rng.choice([0, 0, 1]), single_kernel=rng.choice([0, 1, 2]))
     cam_args = (float(rng.uniform(0, 360)), float(rng.uniform(-89, 89)), float(rng.uniform(0.05, 8)))
