@@ -216,7 +216,8 @@ typedef struct rt_tuning {
     int32_t overlap_frames;    /* launches of fewer frames than this run their path-loop kernel on one of two internal
                                   streams, so that consecutive launches (the reference's one frame per display(), c5:706-760)
                                   overlap: the next one starts while the last paths of this one drain; the fold stays on the
-                                  caller's stream.  Default 33; 1 = never overlap; 1025 = always.  Overlapping serves ONE
+                                  caller's stream.  0 (default, and what rt_scene_get_tuning reports for it) = launches of fewer
+                                  than 2^26 samples (1080p: up to 32 frames); 1 = never overlap; 1025 = always.  Overlapping serves ONE
                                   ordinary caller stream per device — the stream of the first rt_render_device /
                                   rt_viewer_display call there; once another stream renders on that device, and for priority
                                   streams, launches run in order on the caller's stream (same images): INTEGRATION.md, "Streams" */

@@ -1456,6 +1456,7 @@ struct rt_scene {
     bool unit_frames_auto = true;              // rt_tuning.unit_frames was left at its default: the unit follows the view
     bool shade_lanes_auto = true;              // rt_tuning.shade_lanes was left at its default: it follows the scene and the mode
     bool launch_frames_auto = true;            // rt_tuning.launch_frames was left at its default: it follows the image size
+    bool overlap_auto = true;                  // rt_tuning.overlap_frames was left at its default: launches overlap by their size in samples
 };
 
 extern "C" {
@@ -1722,6 +1723,20 @@ static int effective_launch_frames(const rt_scene* s, const rt_render_desc* d) {
     return (int)lf;
 }
 
+// Does a launch of `lf` frames overlap its neighbours (two slots, internal streams)?  rt_tuning.overlap_frames when the caller set
+// it (in frames); otherwise by size: below 2^26 samples — 1080p x 32 — the ramp-up and drain that overlapping hides are worth more
+// than the two path loops cost each other.  Config 5, overlap off / on (tools/ov_probe.py, tools/fpc_probe.py): 1080p x 32 frames
+// 5860 / 6030 Mpaths/s, x 64 6040 / 5930; 1280 x 720 x 64 (59 M samples) 5779 / 5954, x 128 5986 / 5895; 512 x 512 x 64 4853 / 5545,
+// x 128 5386 / 5701, x 256 (2^26) 5700 / 5756.
+// A scene with an entry BVH gains far more (its coherent camera-ray kernel runs in what the neighbour's latency-bound path loop
+// leaves idle: the 10 M-triangle scene, 4K x 8 frames, 895 -> 1057 Mpaths/s; x 16 frames 1190 overlapped): every launch its workspace
+// bound allows overlaps there.
+constexpr long long kOverlapMaxSamples = (long long)1 << 26, kOverlapMaxSamplesBig = (long long)1 << 28;
+static bool launch_overlaps(const rt_scene* s, const rt_render_desc* d, int lf) {
+    if (!s->overlap_auto) return lf < s->tuning.overlap_frames;
+    return (long long)d->width * d->height * lf < (s->has_entry ? kOverlapMaxSamplesBig : kOverlapMaxSamples);
+}
+
 static void fill_params(const rt_scene* s, const rt_render_desc* d, RenderParams* P) {
     memset(P, 0, sizeof(*P));
     P->sc = s->dev;
@@ -1936,7 +1951,7 @@ static int scene_workspace(rt_scene* s, const rt_render_desc* d, int frame_count
     // short launches are dominated by ramp-up and drain (a launch ends with every wave finishing its last paths at falling
     // lane utilisation): those overlap their neighbours.  Long launches stay on the caller's stream, one at a time, so that
     // a kernel's duration means what it says (rt_kernel_time_ms, rocprofv3).
-    pipelined = pipelined && launch_frames < s->tuning.overlap_frames;
+    pipelined = pipelined && launch_overlaps(s, d, launch_frames);
     ws->n_slots = pipelined ? 2 : 1;
     ws->next_slot = pipelined ? &s->next_slot : nullptr;
     for (int k = 0; k < ws->n_slots; ++k) {
@@ -2069,6 +2084,7 @@ int rt_scene_get_tuning(const rt_scene* s, rt_tuning* out) {
     if (s->unit_frames_auto) out->unit_frames = 0;  // (0 = chosen per view: a get / modify / set round trip keeps it that way)
     if (s->shade_lanes_auto) out->shade_lanes = 0;  // (0 = chosen per scene and mode)
     if (s->launch_frames_auto) out->launch_frames = 0;  // (0 = chosen per image size)
+    if (s->overlap_auto) out->overlap_frames = 0;       // (0 = by the launch's size in samples)
     return RT_OK;
 }
 
@@ -2100,6 +2116,7 @@ int rt_scene_set_tuning(rt_scene* s, const rt_tuning* t) {
     s->unit_frames_auto = !(t && t->unit_frames > 0);
     s->shade_lanes_auto = !(t && t->shade_lanes > 0);
     s->launch_frames_auto = !(t && t->launch_frames > 0);
+    s->overlap_auto = !(t && t->overlap_frames > 0);
     s->dev.has_entry = (s->has_entry && !n.no_entry_bvh && !n.no_cull) ? 1 : 0;
     return RT_OK;
 }
@@ -2138,7 +2155,7 @@ int rt_scene_launch_shape(const rt_scene* s, const rt_render_desc* d, int frame_
     out->launch_frames = lf;
     out->unit_frames = effective_unit_frames(s, d);
     out->two_kernels = want_seg ? 1 : 0;
-    out->overlapped = lf < s->tuning.overlap_frames ? 1 : 0;
+    out->overlapped = launch_overlaps(s, d, lf) ? 1 : 0;
     out->screen_coverage = screen_coverage(s, d);
     return RT_OK;
 }
@@ -2165,7 +2182,7 @@ int rt_render_device(rt_scene* s, const rt_render_desc* d, int frame_begin, int 
         OverlapOwner& g = g_overlap[s->device];
         if (!g.has_owner) g.owner = (hipStream_t)stream, g.has_owner = true;
         if (g.owner != (hipStream_t)stream) g.disabled = true;
-        overlap = !g.disabled && lf < s->tuning.overlap_frames;
+        overlap = !g.disabled && launch_overlaps(s, d, lf);
     }
     if (overlap && stream) {
         int prio = 0;

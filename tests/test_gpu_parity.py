@@ -1085,7 +1085,7 @@ def test_unit_size_follows_the_view_and_never_changes_the_image(scene_chap4, hdr
 @pytest.mark.library_default_form
 def test_launch_shape_follows_image_size_view_and_call(scene_chap5, hdr_pair):
     """rt_scene_launch_shape reports what rt_tuning leaves to the library: 2^27 samples per launch but at least 64 frames (the
-    workspace bound cuts 4K to 16), two kernels above 2^22 samples per launch, overlap below 33 frames per launch; explicit tuning
+    workspace bound cuts 4K to 16), two kernels above 2^22 samples per launch, overlap below 2^26 samples per launch; explicit tuning
     wins; and a 300-frame call on a small image — one launch now, five before — is still the oracle's image."""
     tris, nodes = scene_chap5
     hdr, cache = hdr_pair
@@ -1101,9 +1101,11 @@ def test_launch_shape_follows_image_size_view_and_call(scene_chap5, hdr_pair):
     assert shape(1920, 1080, 1) == (1, 2, 0, 1)
     assert shape(1920, 1080, 2) == (2, 2, 0, 1) and shape(1920, 1080, 3) == (3, 2, 1, 1)
     assert shape(1280, 720, 1024) == (145, 2, 1, 0)
-    assert shape(512, 512, 1024) == (512, 2, 1, 0) and shape(512, 512, 8) == (8, 2, 0, 1) and shape(512, 512, 40) == (40, 2, 1, 0)
-    assert shape(64, 64, 5000) == (1024, 2, 0, 0)  # (4.2 M samples: exactly 2^22, not above it)
-    assert shape(3840, 2160, 1024) == (16, 2, 1, 1)  # 64 by the rule, 16 by the 12 GB workspace bound
+    assert shape(512, 512, 1024) == (512, 2, 1, 0) and shape(512, 512, 8) == (8, 2, 0, 1) and shape(512, 512, 40) == (40, 2, 1, 1)
+    assert shape(512, 512, 255) == (255, 2, 1, 1) and shape(512, 512, 256) == (256, 2, 1, 0)  # overlap below 2^26 samples per launch
+    assert shape(64, 64, 5000) == (1024, 2, 0, 1)  # (4.2 M samples: exactly 2^22, not above it)
+    assert shape(3840, 2160, 1024) == (16, 2, 1, 0)  # 64 by the rule, 16 by the 12 GB workspace bound
+    assert shape(3840, 2160, 8) == (8, 2, 1, 1)
     sc.set_tuning(launch_frames=7, single_kernel=2, overlap_frames=1)
     assert shape(1920, 1080, 1024) == (7, 2, 1, 0) and sc.tuning().launch_frames == 7
     sc.set_tuning()
