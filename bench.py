@@ -324,7 +324,7 @@ def main():
         kern_ms, launches = timing.avg_ms, timing.launches
         first_ms = float(getattr(timing, "first_avg_ms", 0.0))  # two-kernel form: the camera-ray kernel that precedes the path loop
         clock = timing.shader_clock_mhz
-        # Launches of fewer than rt_tuning.overlap_frames frames overlap their neighbours (two internal streams): the timed region
+        # Small launches (rt_scene_launch_shape: `overlapped`) overlap their neighbours (two internal streams): the timed region
         # above measures that pipeline, but a kernel's event-bracketed duration then covers a window it shares with the next
         # launch.  The roofline needs the kernel's own duration: a few extra steps with overlap off, outside the timed region.
         tun = renderer.scene.tuning()
@@ -404,7 +404,7 @@ def main():
             }
             if overlapped_ms is not None:
                 roof["overlapped_launches"] = {"kernel_ms_in_the_timed_region": overlapped_ms,
-                                               "note": "the timed steps are launches of fewer than rt_tuning.overlap_frames frames: consecutive launches "
+                                               "note": "the timed steps are launches small enough to overlap (rt_scene_launch_shape): consecutive launches "
                                                        "overlap, so `value` is higher than 1 / kernel_ms implies; kernel_ms (and everything derived from "
                                                        "it here) is the kernel's own duration, from 3 launches with overlap off after the timed region"}
             if prof and not fresh:
